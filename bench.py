@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): Mrays/sec (whole node) + ms/frame, 2048^2 image, 64x64 Gaussian grid
+(`volumetric-ray-tracer -g 64 -w 2048`, default --tiles 16, mode-8 packing).
+
+A step = one frame = what the reference times as `TIME:` (main.cpp:260-296): tile binning of all
+Gaussians + render (+ for N > 1: RCCL gather of the tile shards to rank 0 + assembly into raster
+order).  Inputs (scene tables, camera) are resident in HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Extra keys: "roofline" (render kernel: algorithmic HBM bytes per launch
+over its HIP-event duration, next to the VALU-op rate that actually bounds it) and "cpu_baseline"
+(the oracle's SIMD port of the reference's mode 8, timed on this host on a bounded sample).
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_pkg():
+    d = os.path.join(ROOT, "simd-gaussian-ray-tracing_amd")
+    spec = importlib.util.spec_from_file_location("sgrt_amd", os.path.join(d, "__init__.py"),
+                                                  submodule_search_locations=[d])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["sgrt_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TOPS = 78.6        # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-instructions/s (157.3 TFLOP/s / 2)
+
+
+def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
+    """The reference CPU path stand-in (oracle/vrt_cpu_simd.*: own SIMD port of mode 8) on a bounded sample:
+    16 tiles on the tile-grid diagonal, first rows of each; scaled to whole-frame rays by inner-term count."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    O.build()
+    cam, _ = O.cli_camera(w, h)
+    plane = O.camera_plane(cam)
+    og = g.view(O.GAUSSIAN)
+    tiles = O.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, og, O.camera_view(cam))
+    nt = np.diff(tiles["offsets"]).astype(np.float64)
+    tile_px = (w // tiles_n) * (h // tiles_n)
+    frame_terms = float((nt ** 2).sum() * 5 * tile_px)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    subset = np.arange(0, tiles_n * tiles_n, tiles_n + 1, dtype=np.uint32)   # the diagonal: corners + interior
+    tile_w = w // tiles_n
+    # calibrate on one row of each sampled tile, then size the sample for ~15 s
+    t0 = time.perf_counter()
+    _, terms, simd = O.simd_render_tiled(w, h, plane, cam.position[:], og, tiles, subset, cores, max_rows=1)
+    dt = time.perf_counter() - t0
+    rows = int(max(1, min(h // tiles_n, round(12.0 / max(dt, 1e-3)))))
+    t0 = time.perf_counter()
+    _, terms, simd = O.simd_render_tiled(w, h, plane, cam.position[:], og, tiles, subset, cores, max_rows=rows)
+    dt = time.perf_counter() - t0
+    sample_rays = len(subset) * rows * tile_w
+    terms_per_s = terms / dt
+    frame_s = frame_terms / terms_per_s
+    return {
+        "value": (w * h) / frame_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": (f"{len(subset)} diagonal tiles x first {rows} pixel rows = {sample_rays} rays, {terms:.3e} "
+                   f"(ray,i,k,j) inner terms in {dt:.2f} s ({terms_per_s:.3e} terms/s, SIMD width {simd}); frame = "
+                   f"{frame_terms:.3e} terms -> {frame_s:.1f} s/frame extrapolated by term count{budget_note}"),
+        "ms_per_frame_extrapolated": frame_s * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--tiles", type=int, default=16)
+    ap.add_argument("--cull-eps", type=float, default=1e-9)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plane-arrays", action="store_true", help="feed reference-style plane arrays (12 B/ray reads)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = load_pkg()
+    from sgrt_amd import scene
+
+    w = h = args.width
+    g = scene.grid_scene(args.grid)
+    cam, _ = scene.cli_camera(w, h)
+    origin = cam.position
+    view = cam.view
+    tw = th = 2.0 / args.tiles
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+
+    r = pkg.Renderer(local_rank)
+    r.set_gaussians(g)
+    if args.plane_arrays:
+        r.set_plane(w, h, *cam.plane())
+    else:
+        r.set_camera(w, h, cam.position, cam.right, cam.up, cam.front, float(cam.focal))
+    r.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
+    r.set_shard(rank, world)
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    r.tile_gaussians_device(tw, th, view, sp)   # also sizes the tile grid (one-time host sync)
+    torch.cuda.synchronize()
+
+    image = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    if world > 1:
+        npx = r.shard_pixels()
+        shard = [torch.zeros(npx, dtype=torch.int32, device="cuda") for _ in range(2)]
+        gathered = [torch.zeros(npx * world, dtype=torch.int32, device="cuda") if rank == 0 else None for _ in range(2)]
+        glist = [list(gt.chunk(world)) if gt is not None else None for gt in gathered]
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def run(nsteps, timed):
+        pending = [None, None]
+        for k in range(nsteps):
+            r.tile_gaussians_device(tw, th, view, sp)
+            if timed:
+                ev[k][0].record(stream)
+            if world == 1:
+                r.render_device(origin, pack, image.data_ptr(), 0, sp)
+                if timed:
+                    ev[k][1].record(stream)
+            else:
+                b = k & 1
+                if pending[b] is not None:
+                    pending[b].wait()
+                r.render_shard_device(origin, pack, shard[b].data_ptr(), sp)
+                if timed:
+                    ev[k][1].record(stream)
+                pending[b] = dist.gather(shard[b], glist[b], dst=0, async_op=True)
+                if k >= 1 and pending[1 - b] is not None:
+                    pending[1 - b].wait()
+                    if rank == 0:
+                        r.assemble_shards_device(gathered[1 - b].data_ptr(), image.data_ptr(), sp)
+                    pending[1 - b] = None
+        if world > 1 and nsteps:
+            b = (nsteps - 1) & 1
+            if pending[b] is not None:
+                pending[b].wait()
+                if rank == 0:
+                    r.assemble_shards_device(gathered[b].data_ptr(), image.data_ptr(), sp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    kernel_ms = float(kern_ms.item())
+
+    if rank == 0:
+        rays = w * h * args.steps
+        ms_per_step = elapsed / args.steps * 1e3
+        # ---- render-kernel roofline (DESIGN.md "Measurement") ----
+        # algorithmic HBM bytes per launch: 4 B/ray framebuffer write (+12 B/ray plane read in
+        # --plane-arrays mode) + the scene tables once (64 B/Gaussian) + the tile index lists once (4 B/entry)
+        counts = r.tile_counts()
+        n_entries = int(counts.sum())
+        rays_launch = (w * h) // world if world > 1 else w * h
+        alg_bytes = rays_launch * (4 + (12 if args.plane_arrays else 0)) + 64 * len(g) + 4 * n_entries // world
+        achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # VALU accounting from a stats pass (outside the timed region)
+        r.enable_stats(True)
+        sub_img, _ = None, None
+        r.set_shard(0, 1)
+        _img, _ = r.render(origin, pack, want_radiance=False)
+        st = r.stats()
+        r.enable_stats(False)
+        r.set_shard(rank, world)
+        result = {
+            "metric": "Mrays/sec (whole node), 2048^2 image, 64x64 Gaussian grid", "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"-g {args.grid} -w {w} (tiles {args.tiles}, mode-8 packing, cull_eps {args.cull_eps:g}, "
+                                   f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
+                       "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
+                       "parallelism": f"tile-shard x{world}" + (" + RCCL gather" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4); see valu"},
+            "valu": {"blocks": st["blocks"], "mean_block_list": st["list_entries"] / max(st["blocks"], 1),
+                     "mean_tile_list": st["tile_entries"] / max(st["blocks"], 1), "overflow_blocks": st["overflow_blocks"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(scene, g, w, h, args.tiles, args.grid, "")
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    barrier()
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * vrt_hip.h -- C ABI of libvrt_hip.so: the MI355X (gfx950) implementation of the
+ * reference's render / radiance / transmittance path.
+ *
+ * The reference has no FFI layer: the path is a set of C++ header templates in
+ * namespace vrt (src/vrt/rt.h:16-405) instantiated by its callers
+ * (src/volumetric-ray-tracer/main.cpp:271-292, tests/transmittance.cpp:27-30,
+ * tests/img-error.cpp:34-43).  Each entry point below names the reference
+ * interface it replaces.  The C++ header include/vrt/vrt.hpp re-creates the
+ * vrt:: signatures on top of this ABI; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - every function returns VRT_HIP_OK (0) or a negative vrt_hip_status; nothing
+ *     exits the process (the reference _exit(1)s, include/definitions.h:23-30).
+ *     vrt_hip_last_error() gives the message of the last failure of a context.
+ *   - the caller owns every host pointer; set_* calls copy; nothing is retained.
+ *   - a context is bound to one device and is not thread-safe (the reference
+ *     renders from one thread, main.cpp:257-296).
+ *   - *_device variants take DEVICE pointers and a hipStream_t (as void*) and are
+ *     asynchronous; the others take HOST pointers and return after completion.
+ *
+ * All paths are relative to /root/reference/src.
+ */
+#ifndef VRT_HIP_H
+#define VRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrt_hip_ctx vrt_hip_ctx;
+
+typedef enum {
+    VRT_HIP_OK = 0,
+    VRT_HIP_ERR_INVALID = -1,   /* bad argument / call order            */
+    VRT_HIP_ERR_HIP = -2,       /* a HIP runtime call failed             */
+    VRT_HIP_ERR_NO_DEVICE = -3, /* no gfx950 device / no GPU             */
+    VRT_HIP_ERR_NOMEM = -4
+} vrt_hip_status;
+
+/* Exp / Erf template arguments of the reference (rt.h:32,61,102,205,315,344;
+ * defaults approx.h:110-127).  LIBM = expf/erff (rt.h:32 defaults), VCL = vcl_exp
+ * (approx.h:91-106; ~1 ulp, flushes to 0 below -87.3), AS = Abramowitz-Stegun
+ * (approx.cpp:90-110).  The others are the alternates of approx.cpp:9-188. */
+enum { VRT_EXP_LIBM = 0, VRT_EXP_VCL = 1, VRT_EXP_FAST = 2, VRT_EXP_SPLINE = 3 };
+enum { VRT_ERF_LIBM = 0, VRT_ERF_AS = 1, VRT_ERF_SPLINE = 2, VRT_ERF_SPLINE_MIRROR = 3, VRT_ERF_TAYLOR = 4 };
+
+/* Pixel packing (rt.h:239-243 / 329-333 / 373-377): u32 = A<<24 | R<<16 | G<<8 | B. */
+enum {
+    VRT_PACK_TRUNC = 0,     /* (u32)(min(c,1)*255): scalar render_image, rt.h:240-242, 280-282        */
+    VRT_PACK_ROUND = 1,     /* round-to-nearest-even (cvts): simd_render_image, rt.h:330-332, 374-376  */
+    VRT_ALPHA_OPAQUE = 0,   /* A = 0xFF: rt.h:239, 279, 329                                           */
+    VRT_ALPHA_COMPUTED = 2  /* A = round(min(1, sum albedo.w*inner)*255): tiled simd_render_image, rt.h:373 */
+};
+
+/* -------- context ---------------------------------------------------------------- */
+/* Creates a context on HIP device `device`.  Fails with VRT_HIP_ERR_NO_DEVICE when no
+ * GPU is visible -- there is no CPU fallback. */
+int vrt_hip_create(int device, vrt_hip_ctx **out);
+void vrt_hip_destroy(vrt_hip_ctx *ctx);
+const char *vrt_hip_last_error(const vrt_hip_ctx *ctx); /* ctx may be NULL: last create() error */
+const char *vrt_hip_version(void);
+
+/* -------- scene: replaces gaussians_t / gaussian_vec_t (types.h:232-270) ----------- */
+/* SoA upload == gaussian_vec_t::from_gaussians / load_gaussians (types.cpp:8-76).
+ * albedo_a may be NULL (treated as 1, like simd_radiance rt.h:176).  n may be 0. */
+int vrt_hip_set_gaussians(vrt_hip_ctx *ctx, size_t n, const float *mu_x, const float *mu_y, const float *mu_z,
+                          const float *albedo_r, const float *albedo_g, const float *albedo_b,
+                          const float *albedo_a, const float *sigma, const float *magnitude);
+/* AoS upload == std::vector<gaussian_t> (types.h:195-200: albedo[4], mu[4], sigma, magnitude; 40 B). */
+int vrt_hip_set_gaussians_aos(vrt_hip_ctx *ctx, size_t n, const void *gaussians);
+
+/* -------- tiling: replaces tile_gaussians + tiles_t (rt.cpp:29-69, types.h:272-287) - */
+/* On-device binning with the reference's exact inclusion test, from the camera's view
+ * matrix (column-major float[16], glm::mat4 layout).  tiles.w/h = ceil(2/tw), ceil(2/th). */
+int vrt_hip_tile_gaussians(vrt_hip_ctx *ctx, float tw, float th, const float view[16]);
+/* Same, asynchronous on `hip_stream` (no host synchronisation once tw/th have been seen before):
+ * the per-frame form for animation loops (main.cpp:263 runs it every frame). */
+int vrt_hip_tile_gaussians_device(vrt_hip_ctx *ctx, float tw, float th, const float view[16], void *hip_stream);
+/* Caller-made tile sets as index lists into the uploaded scene: tile t (row-major,
+ * tidx = ty*tiles_w + tx, rt.cpp:47-51) holds indices[offsets[t] .. offsets[t+1]). */
+int vrt_hip_set_tiles(vrt_hip_ctx *ctx, float tw, float th, uint64_t tiles_w, uint64_t tiles_h,
+                      const uint32_t *offsets, const uint32_t *indices);
+/* Untiled rendering (the gaussians_t overloads, rt.h:227-228, 315-316): every ray sees every Gaussian. */
+int vrt_hip_clear_tiles(vrt_hip_ctx *ctx);
+/* Copies the current per-tile counts (tiles_w*tiles_h entries) to the host; for tests/statistics. */
+int vrt_hip_get_tile_counts(vrt_hip_ctx *ctx, uint32_t *counts, size_t cap, uint64_t *tiles_w, uint64_t *tiles_h);
+/* Copies tile t's index list (ascending scene order, like rt.cpp:52-62) to the host. */
+int vrt_hip_get_tile_indices(vrt_hip_ctx *ctx, uint64_t t, uint32_t *indices, size_t cap, uint32_t *count);
+
+/* -------- rays: replaces camera_t::projection_plane (camera.h:28-33, camera.cpp:50-71) */
+/* Reference-style ray source: three w*h arrays of world-space plane points; ray i has
+ * direction normalize(plane[i] - origin) (rt.h:231-237, 321-326, 366-371). */
+int vrt_hip_set_plane(vrt_hip_ctx *ctx, uint32_t w, uint32_t h, const float *xs, const float *ys, const float *zs);
+/* In-kernel ray generation from the camera basis: plane(i,j) = pos + x*right + y*up - focal*front,
+ * x = -1 + j/(w/2), y = -1 + i/(h/2) -- the closed form of camera.cpp:52,60-69 (no 12 B/ray read). */
+int vrt_hip_set_camera(vrt_hip_ctx *ctx, uint32_t w, uint32_t h, const float pos[3], const float right[3],
+                       const float up[3], const float front[3], float focal);
+
+/* -------- options ---------------------------------------------------------------------- */
+/* exp_kind / erf_kind: the reference's template arguments.  cull_eps: Gaussians whose
+ * sigma*magnitude*exp(-d^2/(2 sigma^2)) is below cull_eps for every ray of an 8x8 pixel
+ * block are skipped for that block (0 disables culling and reproduces the reference's
+ * full O(5 N^2) sum).  Defaults: VRT_EXP_VCL, VRT_ERF_AS, cull_eps = 1e-9. */
+int vrt_hip_set_options(vrt_hip_ctx *ctx, int exp_kind, int erf_kind, float cull_eps);
+
+/* -------- render: replaces render_image / simd_render_image (rt.h:227-404) ------------- */
+/* Renders the current scene/tiles/rays.  image_out: w*h u32 (nullable); radiance_out:
+ * w*h*4 f32 = broadcast_radiance's vec4 per pixel before clamping (nullable).
+ * Returns 0 when finished (the reference returns false = "not aborted"). */
+int vrt_hip_render(vrt_hip_ctx *ctx, const float origin[3], int pack_flags, uint32_t *image_out, float *radiance_out);
+int vrt_hip_render_device(vrt_hip_ctx *ctx, const float origin[3], int pack_flags, uint32_t *d_image,
+                          float *d_radiance, void *hip_stream);
+
+/* Multi-GPU tile sharding: the context renders only tiles t with shard_of(t) == rank.
+ * Owned tiles are written tile-major into a compact buffer of
+ * vrt_hip_shard_pixels() u32s: [local tile][tile_h][tile_w].  assemble() scatters the
+ * rank-major concatenation of all shards (e.g. an RCCL gather result) into raster order. */
+int vrt_hip_set_shard(vrt_hip_ctx *ctx, int rank, int world);
+size_t vrt_hip_shard_pixels(const vrt_hip_ctx *ctx);
+int vrt_hip_render_shard_device(vrt_hip_ctx *ctx, const float origin[3], int pack_flags, uint32_t *d_shard,
+                                void *hip_stream);
+int vrt_hip_assemble_shards_device(vrt_hip_ctx *ctx, const uint32_t *d_gathered, uint32_t *d_image, void *hip_stream);
+
+/* -------- point queries: replace transmittance / radiance (rt.h:32-54, 146-223) ----------- */
+/* T_out[k] = transmittance<Exp,Erf>(o, n, s[k], all Gaussians of the scene), rt.h:32-54. */
+int vrt_hip_transmittance(vrt_hip_ctx *ctx, const float o[3], const float n[3], const float *s, size_t ns,
+                          float *T_out);
+/* out[4*r..] = radiance / broadcast_radiance (rt.h:146-164, 205-223) for ray r with origin
+ * origins[3*r..], unit direction dirs[3*r..], over all Gaussians of the scene (no tiling). */
+int vrt_hip_radiance(vrt_hip_ctx *ctx, size_t nrays, const float *origins, const float *dirs, float *out);
+/* Numeric cross-checks of rt.cpp:8-27 (transmittance_step uses fast_exp like the reference). */
+int vrt_hip_transmittance_step(vrt_hip_ctx *ctx, const float o[3], const float n[3], const float *s, size_t ns,
+                               float delta, float *T_out);
+int vrt_hip_density(vrt_hip_ctx *ctx, size_t npts, const float *pts, float *D_out);
+
+/* -------- elementwise approximations (approx.cpp) on device; for the accuracy study ------ */
+int vrt_hip_eval_erf(vrt_hip_ctx *ctx, int erf_kind, const float *x, size_t n, float *y);
+int vrt_hip_eval_exp(vrt_hip_ctx *ctx, int exp_kind, const float *x, size_t n, float *y);
+
+/* -------- statistics of the last render ----------------------------------------------------- */
+typedef struct {
+    double kernel_ms;        /* render kernel time of the last vrt_hip_render() (HIP events)       */
+    double tiling_ms;        /* last vrt_hip_tile_gaussians() device time                           */
+    uint64_t rays;           /* rays shaded                                                         */
+    uint64_t blocks;         /* 8x8 pixel blocks (one wavefront each)                                */
+    uint64_t list_entries;   /* sum over blocks of candidates kept by the block cull                 */
+    uint64_t tile_entries;   /* sum over blocks of their reference-tile list length                  */
+    uint64_t overflow_blocks;/* blocks whose candidate list overflowed LDS (fell back to tile list)  */
+} vrt_hip_stats;
+int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
+/* Enables per-block statistics collection (small atomics; off by default). */
+int vrt_hip_enable_stats(vrt_hip_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

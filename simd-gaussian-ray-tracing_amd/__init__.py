@@ -1,0 +1,274 @@
+"""MI355X-native volumetric Gaussian ray tracer: Python (ctypes) face of libvrt_hip.so.
+
+The product is the C-ABI shared library built from csrc/ (include/vrt_hip.h); this module is
+only the thin binding the tests, bench.py and the smoke entry use.  It mirrors the reference's
+operator set for the hot path -- render_image / simd_render_image, radiance, transmittance,
+tile_gaussians (reference src/vrt/rt.h, rt.cpp) -- and fails loudly when the HIP library or a
+GPU is missing: there is no CPU fallback.
+
+The directory name contains '-', so import it through `load()` in tests/conftest.py /
+__graft_entry__.py (importlib by path) under the module name `sgrt_amd`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvrt_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+EXP_LIBM, EXP_VCL, EXP_FAST, EXP_SPLINE = 0, 1, 2, 3
+ERF_LIBM, ERF_AS, ERF_SPLINE, ERF_SPLINE_MIRROR, ERF_TAYLOR = 0, 1, 2, 3, 4
+PACK_TRUNC, PACK_ROUND, ALPHA_OPAQUE, ALPHA_COMPUTED = 0, 1, 0, 2
+
+_lib = None
+
+
+class VrtHipError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("tiling_ms", C.c_double), ("rays", C.c_uint64), ("blocks", C.c_uint64),
+                ("list_entries", C.c_uint64), ("tile_entries", C.c_uint64), ("overflow_blocks", C.c_uint64)]
+
+
+def build(verbose=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=out)
+    return LIB_PATH
+
+
+# every symbol include/vrt_hip.h declares: (restype, argtypes)
+_f32p, _u32p, _vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+SYMBOLS = {
+    "vrt_hip_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "vrt_hip_destroy": (None, [_vp]),
+    "vrt_hip_last_error": (C.c_char_p, [_vp]),
+    "vrt_hip_version": (C.c_char_p, []),
+    "vrt_hip_set_gaussians": (C.c_int, [_vp, C.c_size_t] + [_f32p] * 9),
+    "vrt_hip_set_gaussians_aos": (C.c_int, [_vp, C.c_size_t, _vp]),
+    "vrt_hip_tile_gaussians": (C.c_int, [_vp, C.c_float, C.c_float, _f32p]),
+    "vrt_hip_tile_gaussians_device": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _vp]),
+    "vrt_hip_set_tiles": (C.c_int, [_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _u32p, _u32p]),
+    "vrt_hip_clear_tiles": (C.c_int, [_vp]),
+    "vrt_hip_get_tile_counts": (C.c_int, [_vp, _u32p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vrt_hip_get_tile_indices": (C.c_int, [_vp, C.c_uint64, _u32p, C.c_size_t, _u32p]),
+    "vrt_hip_set_plane": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p, _f32p, _f32p]),
+    "vrt_hip_set_camera": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p, _f32p, _f32p, _f32p, C.c_float]),
+    "vrt_hip_set_options": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float]),
+    "vrt_hip_render": (C.c_int, [_vp, _f32p, C.c_int, _u32p, _f32p]),
+    "vrt_hip_render_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp, _vp]),
+    "vrt_hip_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "vrt_hip_shard_pixels": (C.c_size_t, [_vp]),
+    "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
+    "vrt_hip_assemble_shards_device": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "vrt_hip_transmittance": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, _f32p]),
+    "vrt_hip_radiance": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p]),
+    "vrt_hip_transmittance_step": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, C.c_float, _f32p]),
+    "vrt_hip_density": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p]),
+    "vrt_hip_eval_erf": (C.c_int, [_vp, C.c_int, _f32p, C.c_size_t, _f32p]),
+    "vrt_hip_eval_exp": (C.c_int, [_vp, C.c_int, _f32p, C.c_size_t, _f32p]),
+    "vrt_hip_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "vrt_hip_enable_stats": (C.c_int, [_vp, C.c_int]),
+}
+
+
+def lib():
+    """dlopen libvrt_hip.so; raises if it has not been built (never falls back to anything)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VrtHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _f3(v):
+    return np.ascontiguousarray(np.asarray(v, np.float32)[:3])
+
+
+class Renderer:
+    """One context = one GPU.  Mirrors the reference call set (main.cpp:257-296)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = _vp()
+        rc = self._L.vrt_hip_create(device, C.byref(h))
+        if rc != 0:
+            raise VrtHipError(f"vrt_hip_create({device}) failed ({rc}): {self._L.vrt_hip_last_error(None).decode()}")
+        self._h = h
+        self.n = 0
+        self.w = self.h = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vrt_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise VrtHipError(f"{what} failed ({rc}): {self._L.vrt_hip_last_error(self._h).decode()}")
+
+    # ---- scene ----
+    def set_gaussians(self, g):
+        """g: structured array with fields albedo[4], mu[4], sigma, magnitude (gaussian_t, types.h:195-200)."""
+        g = np.ascontiguousarray(g)
+        assert g.dtype.itemsize == 40
+        self.n = len(g)
+        self._chk(self._L.vrt_hip_set_gaussians_aos(self._h, len(g), g.ctypes.data), "set_gaussians_aos")
+
+    def set_gaussians_soa(self, mu, albedo, sigma, magnitude, alpha=None):
+        mu = np.asarray(mu, np.float32)
+        albedo = np.asarray(albedo, np.float32)
+        cols = [np.ascontiguousarray(mu[:, i]) for i in range(3)] + [np.ascontiguousarray(albedo[:, i]) for i in range(3)]
+        a = None if alpha is None else np.ascontiguousarray(alpha, np.float32)
+        s = np.ascontiguousarray(sigma, np.float32)
+        m = np.ascontiguousarray(magnitude, np.float32)
+        self.n = len(s)
+        self._chk(self._L.vrt_hip_set_gaussians(self._h, len(s), *[_fp(c) for c in cols], None if a is None else _fp(a),
+                                                _fp(s), _fp(m)), "set_gaussians")
+
+    # ---- tiles ----
+    def tile_gaussians(self, tw, th, view):
+        v = np.ascontiguousarray(view, np.float32).ravel()
+        assert v.size == 16
+        self._chk(self._L.vrt_hip_tile_gaussians(self._h, tw, th, _fp(v)), "tile_gaussians")
+
+    def tile_gaussians_device(self, tw, th, view, stream=0):
+        v = np.ascontiguousarray(view, np.float32).ravel()
+        self._chk(self._L.vrt_hip_tile_gaussians_device(self._h, tw, th, _fp(v), stream or None), "tile_gaussians_device")
+
+    def set_tiles(self, tiles):
+        off = np.ascontiguousarray(tiles["offsets"], np.uint32)
+        idx = np.ascontiguousarray(tiles["indices"], np.uint32)
+        self._chk(self._L.vrt_hip_set_tiles(self._h, float(tiles["tw"]), float(tiles["th"]), int(tiles["w"]),
+                                            int(tiles["h"]), off.ctypes.data_as(_u32p),
+                                            idx.ctypes.data_as(_u32p) if idx.size else None), "set_tiles")
+
+    def clear_tiles(self):
+        self._chk(self._L.vrt_hip_clear_tiles(self._h), "clear_tiles")
+
+    def tile_counts(self):
+        tw, th = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.vrt_hip_get_tile_counts(self._h, None, 0, C.byref(tw), C.byref(th)), "get_tile_counts")
+        counts = np.zeros(tw.value * th.value, np.uint32)
+        self._chk(self._L.vrt_hip_get_tile_counts(self._h, counts.ctypes.data_as(_u32p), counts.size, None, None),
+                  "get_tile_counts")
+        return counts.reshape(th.value, tw.value)
+
+    def tile_indices(self, t):
+        cnt = C.c_uint32()
+        self._chk(self._L.vrt_hip_get_tile_indices(self._h, t, None, 0, C.byref(cnt)), "get_tile_indices")
+        out = np.zeros(max(cnt.value, 1), np.uint32)
+        self._chk(self._L.vrt_hip_get_tile_indices(self._h, t, out.ctypes.data_as(_u32p), out.size, C.byref(cnt)),
+                  "get_tile_indices")
+        return out[:cnt.value]
+
+    # ---- rays ----
+    def set_plane(self, w, h, xs, ys, zs):
+        xs, ys, zs = (np.ascontiguousarray(a, np.float32) for a in (xs, ys, zs))
+        assert xs.size == ys.size == zs.size == w * h
+        self.w, self.h = w, h
+        self._chk(self._L.vrt_hip_set_plane(self._h, w, h, _fp(xs), _fp(ys), _fp(zs)), "set_plane")
+
+    def set_camera(self, w, h, pos, right, up, front, focal=1.0):
+        self.w, self.h = w, h
+        self._chk(self._L.vrt_hip_set_camera(self._h, w, h, _fp(_f3(pos)), _fp(_f3(right)), _fp(_f3(up)),
+                                             _fp(_f3(front)), focal), "set_camera")
+
+    def set_options(self, exp_kind=EXP_VCL, erf_kind=ERF_AS, cull_eps=1e-9):
+        self._chk(self._L.vrt_hip_set_options(self._h, exp_kind, erf_kind, cull_eps), "set_options")
+
+    # ---- render ----
+    def render(self, origin, pack=PACK_ROUND | ALPHA_COMPUTED, want_radiance=True):
+        """Returns (image u32 [h,w], radiance f32 [h,w,4] or None)."""
+        img = np.zeros(self.w * self.h, np.uint32)
+        rad = np.zeros((self.w * self.h, 4), np.float32) if want_radiance else None
+        self._chk(self._L.vrt_hip_render(self._h, _fp(_f3(origin)), pack, img.ctypes.data_as(_u32p),
+                                         _fp(rad) if rad is not None else None), "render")
+        return img.reshape(self.h, self.w), (rad.reshape(self.h, self.w, 4) if rad is not None else None)
+
+    def render_device(self, origin, pack, d_image, d_radiance=0, stream=0):
+        self._chk(self._L.vrt_hip_render_device(self._h, _fp(_f3(origin)), pack, d_image, d_radiance or None,
+                                                stream or None), "render_device")
+
+    def set_shard(self, rank, world):
+        self._chk(self._L.vrt_hip_set_shard(self._h, rank, world), "set_shard")
+
+    def shard_pixels(self):
+        return self._L.vrt_hip_shard_pixels(self._h)
+
+    def render_shard_device(self, origin, pack, d_shard, stream=0):
+        self._chk(self._L.vrt_hip_render_shard_device(self._h, _fp(_f3(origin)), pack, d_shard, stream or None),
+                  "render_shard_device")
+
+    def assemble_shards_device(self, d_gathered, d_image, stream=0):
+        self._chk(self._L.vrt_hip_assemble_shards_device(self._h, d_gathered, d_image, stream or None),
+                  "assemble_shards_device")
+
+    # ---- point queries ----
+    def transmittance(self, o, n, s):
+        s = np.ascontiguousarray(np.atleast_1d(s), np.float32)
+        out = np.zeros_like(s)
+        self._chk(self._L.vrt_hip_transmittance(self._h, _fp(_f3(o)), _fp(_f3(n)), _fp(s), s.size, _fp(out)),
+                  "transmittance")
+        return out
+
+    def transmittance_step(self, o, n, s, delta):
+        s = np.ascontiguousarray(np.atleast_1d(s), np.float32)
+        out = np.zeros_like(s)
+        self._chk(self._L.vrt_hip_transmittance_step(self._h, _fp(_f3(o)), _fp(_f3(n)), _fp(s), s.size, delta,
+                                                     _fp(out)), "transmittance_step")
+        return out
+
+    def density(self, pts):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+        out = np.zeros(len(pts), np.float32)
+        self._chk(self._L.vrt_hip_density(self._h, len(pts), _fp(pts), _fp(out)), "density")
+        return out
+
+    def radiance(self, origins, dirs):
+        origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros((len(dirs), 4), np.float32)
+        self._chk(self._L.vrt_hip_radiance(self._h, len(dirs), _fp(origins), _fp(dirs), _fp(out)), "radiance")
+        return out
+
+    def eval_erf(self, kind, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        self._chk(self._L.vrt_hip_eval_erf(self._h, kind, _fp(x), x.size, _fp(y)), "eval_erf")
+        return y
+
+    def eval_exp(self, kind, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        self._chk(self._L.vrt_hip_eval_exp(self._h, kind, _fp(x), x.size, _fp(y)), "eval_exp")
+        return y
+
+    def enable_stats(self, on=True):
+        self._chk(self._L.vrt_hip_enable_stats(self._h, int(on)), "enable_stats")
+
+    def stats(self):
+        s = Stats()
+        self._chk(self._L.vrt_hip_get_stats(self._h, C.byref(s)), "get_stats")
+        return {k: getattr(s, k) for k, _ in Stats._fields_}

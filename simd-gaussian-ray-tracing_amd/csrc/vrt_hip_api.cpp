@@ -1,0 +1,705 @@
+// vrt_hip_api.cpp -- the C ABI of libvrt_hip.so (see include/vrt_hip.h): context, device-resident
+// scene / tile / ray state, launches.  Compiled with hipcc for gfx950; links only libamdhip64.
+// There is no CPU fallback anywhere in this file: without a GPU vrt_hip_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vrt_hip.h"
+#include "vrt_kernels.h"
+
+using namespace vrtk;
+
+namespace {
+
+std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void **)&p, (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) cap = n ? n : 1;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct vrt_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    // scene (static SoA copy kept so options can be re-applied)
+    uint32_t n = 0;
+    DevBuf<float> soa[9]; // mu_x mu_y mu_z ar ag ab aa sigma mag
+    bool has_alpha = false;
+    DevBuf<float4> mu_sig, gA, gB, gC, gD;
+    DevBuf<uint32_t> iota;
+    bool tables_dirty = true;
+    bool gA_valid = false;
+    float gA_origin[3] = { 0, 0, 0 };
+
+    // tiles
+    bool tiled = false;
+    float tw = 2.f, th = 2.f;
+    uint32_t tiles_w = 1, tiles_h = 1;
+    DevBuf<uint32_t> t_start, t_count, t_indices;
+    DevBuf<float4> proj;
+    DevBuf<float> xc, yc;
+    bool device_binned = false;      // tile lists use the fixed-stride layout of vrt_hip_tile_gaussians
+    float grid_tw = 0.f, grid_th = 0.f;
+    uint32_t grid_n = 0;
+
+    // rays
+    uint32_t w = 0, h = 0;
+    bool plane_mode = false;
+    DevBuf<float> xs, ys, zs;
+    float cam_pos[3] = { 0, 0, 0 }, cam_right[3] = { 1, 0, 0 }, cam_up[3] = { 0, 1, 0 }, cam_front[3] = { 0, 0, -1 };
+    float focal = 1.f;
+    bool rays_set = false;
+
+    // options
+    int exp_kind = VRT_EXP_VCL, erf_kind = VRT_ERF_AS;
+    float cull_eps = 1e-9f;
+
+    // sharding
+    int rank = 0, world = 1;
+    DevBuf<uint32_t> tile_map, slot_tiles;
+    uint32_t n_local = 0, n_slots = 0;
+    bool shard_dirty = true;
+
+    // scratch + statistics
+    DevBuf<uint32_t> d_image;
+    DevBuf<float4> d_rad;
+    DevBuf<unsigned long long> d_stats;
+    bool stats_on = false;
+    vrt_hip_stats last{};
+};
+
+namespace {
+
+int fail(vrt_hip_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail((c), VRT_HIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+float exp_floor_x(int exp_kind)
+{
+    // Exp(-x) is exactly 0 past this point for the chosen Exp, so such Gaussians contribute nothing:
+    // vcl_exp flushes below -87.3 (vectormath_exp.h:393); expf reaches 0 below ~-103.98.
+    switch (exp_kind) {
+    case VRT_EXP_VCL: return 87.3f;
+    case VRT_EXP_LIBM: return 104.f;
+    case VRT_EXP_FAST: return 88.f; // clamped fast_exp returns 0 for x < -87.3 (a*x+b < 2^23)
+    case VRT_EXP_SPLINE: return 9.0f; // spline_exp(x) = 0 for x <= -9 (approx.cpp:143)
+    default: return INFINITY;
+    }
+}
+
+int rebuild_tables(vrt_hip_ctx *c)
+{
+    if (!c->tables_dirty) return VRT_HIP_OK;
+    HIPCHK(c, c->mu_sig.reserve(c->n)); HIPCHK(c, c->gA.reserve(c->n)); HIPCHK(c, c->gB.reserve(c->n));
+    HIPCHK(c, c->gC.reserve(c->n)); HIPCHK(c, c->gD.reserve(c->n)); HIPCHK(c, c->iota.reserve(c->n));
+    launch_build_static(c->n, c->soa[0].p, c->soa[1].p, c->soa[2].p, c->soa[3].p, c->soa[4].p, c->soa[5].p,
+                        c->has_alpha ? c->soa[6].p : nullptr, c->soa[7].p, c->soa[8].p, c->cull_eps,
+                        exp_floor_x(c->exp_kind), c->mu_sig.p, c->gB.p, c->gC.p, c->gD.p, c->stream);
+    launch_iota(c->iota.p, c->n, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // later launches may use a caller's stream
+    c->tables_dirty = false;
+    c->gA_valid = false;
+    return VRT_HIP_OK;
+}
+
+SceneTables tables(const vrt_hip_ctx *c)
+{
+    SceneTables s;
+    s.mu_sig = c->mu_sig.p; s.gA = c->gA.p; s.gB = c->gB.p; s.gC = c->gC.p; s.gD = c->gD.p; s.n = c->n;
+    return s;
+}
+
+int prep_frame(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
+{
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+    if (c->gA_valid && !memcmp(c->gA_origin, origin, 3 * sizeof(float))) return VRT_HIP_OK;
+    launch_prep_frame(tables(c), c->gA.p, origin, st);
+    HIPCHK(c, hipGetLastError());
+    memcpy(c->gA_origin, origin, 3 * sizeof(float));
+    c->gA_valid = true;
+    return VRT_HIP_OK;
+}
+
+// tile geometry for the current image size (rt.h:348-349, 364-365)
+TileLists tile_lists(const vrt_hip_ctx *c)
+{
+    TileLists t;
+    t.start = c->t_start.p; t.count = c->t_count.p;
+    if (c->tiled) {
+        t.indices = c->t_indices.p;
+        t.tiles_w = c->tiles_w; t.tiles_h = c->tiles_h;
+        t.tile_w = (uint32_t)(uint64_t)(c->w * c->tw / 2.f);
+        t.tile_h = (uint32_t)(uint64_t)(c->h * c->th / 2.f);
+    } else {
+        t.indices = c->iota.p;
+        t.tiles_w = t.tiles_h = 1;
+        t.tile_w = c->w; t.tile_h = c->h;
+    }
+    t.stride = t.tile_w * t.tiles_w;
+    return t;
+}
+
+int ensure_untiled_lists(vrt_hip_ctx *c)
+{
+    if (c->tiled) return VRT_HIP_OK;
+    HIPCHK(c, c->t_start.reserve(1)); HIPCHK(c, c->t_count.reserve(1));
+    const uint32_t zero = 0, n = c->n;
+    HIPCHK(c, hipMemcpyAsync(c->t_start.p, &zero, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->t_count.p, &n, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VRT_HIP_OK;
+}
+
+RayGen ray_gen(const vrt_hip_ctx *c, const float origin[3])
+{
+    RayGen r;
+    r.xs = c->plane_mode ? c->xs.p : nullptr; r.ys = c->plane_mode ? c->ys.p : nullptr;
+    r.zs = c->plane_mode ? c->zs.p : nullptr;
+    for (int i = 0; i < 3; ++i) {
+        r.origin[i] = origin[i]; r.pos[i] = c->cam_pos[i]; r.right[i] = c->cam_right[i]; r.up[i] = c->cam_up[i];
+        r.front[i] = c->cam_front[i];
+    }
+    r.focal = c->focal;
+    r.inv_half_w = 1.f / (c->w / 2.f); r.inv_half_h = 1.f / (c->h / 2.f);
+    r.width = c->w; r.height = c->h;
+    return r;
+}
+
+// owner of tile t: diagonal interleave, balanced for centred objects
+inline int shard_owner(uint32_t t, uint32_t tiles_w, int world) { return (int)((t + t / tiles_w) % (uint32_t)world); }
+
+int rebuild_shard(vrt_hip_ctx *c)
+{
+    if (!c->shard_dirty) return VRT_HIP_OK;
+    const uint32_t tiles_w = c->tiled ? c->tiles_w : 1, ntiles = c->tiled ? c->tiles_w * c->tiles_h : 1;
+    std::vector<std::vector<uint32_t>> owned(c->world);
+    for (uint32_t t = 0; t < ntiles; ++t) owned[shard_owner(t, tiles_w, c->world)].push_back(t);
+    size_t slots = 0;
+    for (auto &v : owned) slots = std::max(slots, v.size());
+    std::vector<uint32_t> slot_tiles((size_t)c->world * slots, 0xFFFFFFFFu);
+    for (int r = 0; r < c->world; ++r)
+        for (size_t k = 0; k < owned[r].size(); ++k) slot_tiles[(size_t)r * slots + k] = owned[r][k];
+    c->n_local = (uint32_t)owned[c->rank].size();
+    c->n_slots = (uint32_t)slots;
+    HIPCHK(c, c->tile_map.reserve(c->n_local)); HIPCHK(c, c->slot_tiles.reserve(slot_tiles.size()));
+    if (c->n_local)
+        HIPCHK(c, hipMemcpy(c->tile_map.p, owned[c->rank].data(), c->n_local * 4, hipMemcpyHostToDevice));
+    if (!slot_tiles.empty())
+        HIPCHK(c, hipMemcpy(c->slot_tiles.p, slot_tiles.data(), slot_tiles.size() * 4, hipMemcpyHostToDevice));
+    c->shard_dirty = false;
+    return VRT_HIP_OK;
+}
+
+int check_ready(vrt_hip_ctx *c)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!c->rays_set || !c->w || !c->h) return fail(c, VRT_HIP_ERR_INVALID, "render: call vrt_hip_set_plane/set_camera first");
+    return VRT_HIP_OK;
+}
+
+int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *d_image, float4 *d_rad,
+                  hipStream_t st, bool shard_compact)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = prep_frame(c, origin, st))) return rc;
+    if ((rc = ensure_untiled_lists(c))) return rc;
+    TileLists t = tile_lists(c);
+    if (c->tiled && (t.tile_w == 0 || t.tile_h == 0)) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
+    RenderTarget o;
+    o.image = d_image; o.radiance = d_rad; o.pack_flags = pack_flags;
+    o.stats = c->stats_on ? c->d_stats.p : nullptr;
+    if (c->world > 1 || shard_compact) {
+        if ((rc = rebuild_shard(c))) return rc;
+        o.tile_map = c->tile_map.p; o.n_local_tiles = c->n_local; o.compact = shard_compact ? 1 : 0;
+    } else {
+        o.tile_map = nullptr; o.n_local_tiles = t.tiles_w * t.tiles_h; o.compact = 0;
+    }
+    if (o.stats) HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 3 * sizeof(unsigned long long), st));
+    const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
+    c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
+    c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
+    launch_render(tables(c), t, ray_gen(c, origin), o, c->exp_kind, c->erf_kind, st);
+    HIPCHK(c, hipGetLastError());
+    return VRT_HIP_OK;
+}
+
+} // namespace
+
+// Needed by nothing outside this file; kept out of the anonymous namespace only for clarity.
+extern "C" {
+
+const char *vrt_hip_version(void) { return "vrt_hip 0.1 (gfx950)"; }
+
+int vrt_hip_create(int device, vrt_hip_ctx **out)
+{
+    if (!out) return fail(nullptr, VRT_HIP_ERR_INVALID, "create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, VRT_HIP_ERR_NO_DEVICE, "create: no HIP device visible (libvrt_hip has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(nullptr, VRT_HIP_ERR_INVALID, "create: device index out of range");
+    HIPCHK(nullptr, hipSetDevice(device));
+    vrt_hip_ctx *c = new (std::nothrow) vrt_hip_ctx();
+    if (!c) return fail(nullptr, VRT_HIP_ERR_NOMEM, "create: out of host memory");
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        c->d_stats.reserve(4) != hipSuccess) {
+        delete c;
+        return fail(nullptr, VRT_HIP_ERR_HIP, "create: stream/event creation failed");
+    }
+    *out = c;
+    return VRT_HIP_OK;
+}
+
+void vrt_hip_destroy(vrt_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &b : c->soa) b.release();
+    c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
+    c->t_start.release(); c->t_count.release(); c->t_indices.release(); c->proj.release(); c->xc.release(); c->yc.release();
+    c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
+    c->d_image.release(); c->d_rad.release(); c->d_stats.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *vrt_hip_last_error(const vrt_hip_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const float *mu_y, const float *mu_z,
+                          const float *ar, const float *ag, const float *ab, const float *aa, const float *sigma,
+                          const float *mag)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (n > 0xFFFFFFF0ull) return fail(c, VRT_HIP_ERR_INVALID, "set_gaussians: too many Gaussians");
+    const float *src[9] = { mu_x, mu_y, mu_z, ar, ag, ab, aa, sigma, mag };
+    for (int i = 0; i < 9; ++i)
+        if (n && !src[i] && i != 6) return fail(c, VRT_HIP_ERR_INVALID, "set_gaussians: NULL array");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 9; ++i) {
+        HIPCHK(c, c->soa[i].reserve(n));
+        if (n && src[i]) HIPCHK(c, hipMemcpy(c->soa[i].p, src[i], n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->has_alpha = aa != nullptr;
+    c->n = (uint32_t)n;
+    c->tables_dirty = true;
+    if (!c->tiled) c->shard_dirty = true;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_gaussians_aos(vrt_hip_ctx *c, size_t n, const void *gaussians)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (n && !gaussians) return fail(c, VRT_HIP_ERR_INVALID, "set_gaussians_aos: NULL");
+    // gaussian_t: albedo[4] mu[4] sigma magnitude (types.h:195-200)
+    const float *g = (const float *)gaussians;
+    std::vector<float> soa[9];
+    for (auto &v : soa) v.resize(n ? n : 1);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = g + 10 * i;
+        soa[3][i] = p[0]; soa[4][i] = p[1]; soa[5][i] = p[2]; soa[6][i] = p[3];
+        soa[0][i] = p[4]; soa[1][i] = p[5]; soa[2][i] = p[6];
+        soa[7][i] = p[8]; soa[8][i] = p[9];
+    }
+    return vrt_hip_set_gaussians(c, n, soa[0].data(), soa[1].data(), soa[2].data(), soa[3].data(), soa[4].data(),
+                                 soa[5].data(), soa[6].data(), soa[7].data(), soa[8].data());
+}
+
+int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_eps)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (exp_kind < 0 || exp_kind > VRT_EXP_SPLINE || erf_kind < 0 || erf_kind > VRT_ERF_TAYLOR || !(cull_eps >= 0.f))
+        return fail(c, VRT_HIP_ERR_INVALID, "set_options: bad argument");
+    const bool supported = (erf_kind == VRT_ERF_AS) || (exp_kind == VRT_EXP_VCL) ||
+                           (exp_kind == VRT_EXP_LIBM && erf_kind == VRT_ERF_LIBM);
+    if (!supported) return fail(c, VRT_HIP_ERR_INVALID, "set_options: this Exp/Erf pair is not instantiated");
+    if (exp_kind != c->exp_kind || cull_eps != c->cull_eps) c->tables_dirty = true;
+    c->exp_kind = exp_kind; c->erf_kind = erf_kind; c->cull_eps = cull_eps;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_clear_tiles(vrt_hip_ctx *c)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    c->tiled = false; c->tw = c->th = 2.f; c->tiles_w = c->tiles_h = 1; c->shard_dirty = true;
+    c->device_binned = false;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_tiles(vrt_hip_ctx *c, float tw, float th, uint64_t tiles_w, uint64_t tiles_h, const uint32_t *offsets,
+                      const uint32_t *indices)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!offsets || tiles_w == 0 || tiles_h == 0 || tiles_w * tiles_h > (1u << 24) || !(tw > 0.f) || !(th > 0.f))
+        return fail(c, VRT_HIP_ERR_INVALID, "set_tiles: bad argument");
+    const size_t nt = (size_t)(tiles_w * tiles_h);
+    const size_t total = offsets[nt];
+    if (total && !indices) return fail(c, VRT_HIP_ERR_INVALID, "set_tiles: NULL indices");
+    std::vector<uint32_t> start(nt), count(nt);
+    for (size_t t = 0; t < nt; ++t) {
+        if (offsets[t + 1] < offsets[t]) return fail(c, VRT_HIP_ERR_INVALID, "set_tiles: offsets not monotone");
+        start[t] = offsets[t]; count[t] = offsets[t + 1] - offsets[t];
+    }
+    for (size_t k = 0; k < total; ++k)
+        if (indices[k] >= c->n) return fail(c, VRT_HIP_ERR_INVALID, "set_tiles: index out of range (upload the scene first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->t_start.reserve(nt)); HIPCHK(c, c->t_count.reserve(nt)); HIPCHK(c, c->t_indices.reserve(total));
+    HIPCHK(c, hipMemcpy(c->t_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->t_count.p, count.data(), nt * 4, hipMemcpyHostToDevice));
+    if (total) HIPCHK(c, hipMemcpy(c->t_indices.p, indices, total * 4, hipMemcpyHostToDevice));
+    c->tiled = true; c->tw = tw; c->th = th; c->tiles_w = (uint32_t)tiles_w; c->tiles_h = (uint32_t)tiles_h;
+    c->shard_dirty = true;
+    c->device_binned = false;
+    return VRT_HIP_OK;
+}
+
+// (Re)builds the tile-centre arrays and fixed-stride list starts when the tile grid changes.
+static int prepare_tile_grid(vrt_hip_ctx *c, float tw, float th)
+{
+    // tile centres by the reference's float loops (rt.cpp:47-49); tiles_t.w/h = ceil(2/t) (types.h:280)
+    std::vector<float> xc, yc;
+    for (float x = -1.f + tw / 2; x < 1.f; x += tw) { xc.push_back(x); if (xc.size() > 4096) break; }
+    for (float y = -1.f + th / 2; y < 1.f; y += th) { yc.push_back(y); if (yc.size() > 4096) break; }
+    const uint32_t tiles_w = (uint32_t)std::ceil(2.f / tw), tiles_h = (uint32_t)std::ceil(2.f / th);
+    if (xc.size() > 4096 || yc.size() > 4096 || tiles_w > 4096 || tiles_h > 4096)
+        return fail(c, VRT_HIP_ERR_INVALID, "tile_gaussians: more than 4096 tiles per axis");
+    // The reference indexes tiles.gaussians[ty*tiles.w + tx] for ty < tiles.h, tx < tiles.w (rt.h:356) while the
+    // float loops produced xc.size() tiles per row; they agree unless 2/t is not representable.  Keep tiles.w x
+    // tiles.h tiles, each tested against the centre the loops would have produced for that row/column.
+    while (xc.size() < tiles_w) xc.push_back(xc.empty() ? -1.f + tw / 2 : xc.back() + tw);
+    while (yc.size() < tiles_h) yc.push_back(yc.empty() ? -1.f + th / 2 : yc.back() + th);
+    const size_t nt = (size_t)tiles_w * tiles_h;
+    if (nt * (size_t)c->n > (size_t)1 << 31) return fail(c, VRT_HIP_ERR_NOMEM, "tile_gaussians: tiles x gaussians too large");
+    HIPCHK(c, c->xc.reserve(tiles_w)); HIPCHK(c, c->yc.reserve(tiles_h)); HIPCHK(c, c->proj.reserve(c->n));
+    HIPCHK(c, c->t_start.reserve(nt)); HIPCHK(c, c->t_count.reserve(nt)); HIPCHK(c, c->t_indices.reserve(nt * c->n));
+    std::vector<uint32_t> start(nt);
+    for (size_t t = 0; t < nt; ++t) start[t] = (uint32_t)(t * c->n);
+    HIPCHK(c, hipMemcpy(c->xc.p, xc.data(), tiles_w * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->yc.p, yc.data(), tiles_h * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->t_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
+    c->grid_tw = tw; c->grid_th = th; c->grid_n = c->n;
+    if (!c->tiled || c->tiles_w != tiles_w || c->tiles_h != tiles_h) c->shard_dirty = true;
+    c->tiled = true; c->tw = tw; c->th = th; c->tiles_w = tiles_w; c->tiles_h = tiles_h;
+    c->device_binned = true;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_tile_gaussians_device(vrt_hip_ctx *c, float tw, float th, const float view[16], void *hip_stream)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!view || !(tw > 0.f) || !(th > 0.f)) return fail(c, VRT_HIP_ERR_INVALID, "tile_gaussians: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+    if (!c->device_binned || c->grid_tw != tw || c->grid_th != th || c->grid_n != c->n) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = prepare_tile_grid(c, tw, th))) return rc;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    launch_project(tables(c), view, c->proj.p, st);
+    launch_bin_tiles(c->proj.p, c->n, c->xc.p, c->yc.p, c->tiles_w, c->tiles_h, tw, th, c->t_indices.p, c->t_count.p, st);
+    HIPCHK(c, hipGetLastError());
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_tile_gaussians(vrt_hip_ctx *c, float tw, float th, const float view[16])
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    int rc = vrt_hip_tile_gaussians_device(c, tw, th, view, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last.tiling_ms = ms;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_get_tile_counts(vrt_hip_ctx *c, uint32_t *counts, size_t cap, uint64_t *tiles_w, uint64_t *tiles_h)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!c->tiled) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_counts: no tiles set");
+    const size_t nt = (size_t)c->tiles_w * c->tiles_h;
+    if (tiles_w) *tiles_w = c->tiles_w;
+    if (tiles_h) *tiles_h = c->tiles_h;
+    if (counts) {
+        if (cap < nt) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_counts: buffer too small");
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(counts, c->t_count.p, nt * 4, hipMemcpyDeviceToHost));
+    }
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_get_tile_indices(vrt_hip_ctx *c, uint64_t t, uint32_t *indices, size_t cap, uint32_t *count)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!c->tiled || t >= (uint64_t)c->tiles_w * c->tiles_h) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_indices: bad tile");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t start = 0, cnt = 0;
+    HIPCHK(c, hipMemcpy(&start, c->t_start.p + t, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&cnt, c->t_count.p + t, 4, hipMemcpyDeviceToHost));
+    if (count) *count = cnt;
+    if (indices) {
+        if (cap < cnt) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_indices: buffer too small");
+        if (cnt) HIPCHK(c, hipMemcpy(indices, c->t_indices.p + start, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    }
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_plane(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float *xs, const float *ys, const float *zs)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!w || !h || !xs || !ys || !zs) return fail(c, VRT_HIP_ERR_INVALID, "set_plane: bad argument");
+    const size_t n = (size_t)w * h;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->xs.reserve(n)); HIPCHK(c, c->ys.reserve(n)); HIPCHK(c, c->zs.reserve(n));
+    HIPCHK(c, hipMemcpy(c->xs.p, xs, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ys.p, ys, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->zs.p, zs, n * 4, hipMemcpyHostToDevice));
+    c->w = w; c->h = h; c->plane_mode = true; c->rays_set = true;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_camera(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float pos[3], const float right[3],
+                       const float up[3], const float front[3], float focal)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!w || !h || !pos || !right || !up || !front) return fail(c, VRT_HIP_ERR_INVALID, "set_camera: bad argument");
+    memcpy(c->cam_pos, pos, 12); memcpy(c->cam_right, right, 12); memcpy(c->cam_up, up, 12); memcpy(c->cam_front, front, 12);
+    c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->rays_set = true;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_render_device(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *d_image, float *d_radiance,
+                          void *hip_stream)
+{
+    if (!c || !origin) return VRT_HIP_ERR_INVALID;
+    return render_common(c, origin, pack_flags, d_image, (float4 *)d_radiance, (hipStream_t)hip_stream, false);
+}
+
+int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *image_out, float *radiance_out)
+{
+    if (!c || !origin) return VRT_HIP_ERR_INVALID;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)c->w * c->h;
+    HIPCHK(c, c->d_image.reserve(npix));
+    if (radiance_out) HIPCHK(c, c->d_rad.reserve(npix));
+    HIPCHK(c, hipMemsetAsync(c->d_image.p, 0, npix * 4, c->stream));
+    if (radiance_out) HIPCHK(c, hipMemsetAsync(c->d_rad.p, 0, npix * 16, c->stream));
+    // tables / frame prep outside the timed kernel window
+    if ((rc = prep_frame(c, origin, c->stream))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    rc = render_common(c, origin, pack_flags, c->d_image.p, radiance_out ? c->d_rad.p : nullptr, c->stream, false);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last.kernel_ms = ms;
+    if (c->stats_on) {
+        unsigned long long st[3];
+        HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
+        c->last.list_entries = st[0]; c->last.tile_entries = st[1]; c->last.overflow_blocks = st[2];
+    }
+    if (image_out) HIPCHK(c, hipMemcpy(image_out, c->d_image.p, npix * 4, hipMemcpyDeviceToHost));
+    if (radiance_out) HIPCHK(c, hipMemcpy(radiance_out, c->d_rad.p, npix * 16, hipMemcpyDeviceToHost));
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_shard(vrt_hip_ctx *c, int rank, int world)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, VRT_HIP_ERR_INVALID, "set_shard: bad rank/world");
+    c->rank = rank; c->world = world; c->shard_dirty = true;
+    return VRT_HIP_OK;
+}
+
+size_t vrt_hip_shard_pixels(const vrt_hip_ctx *cc)
+{
+    vrt_hip_ctx *c = const_cast<vrt_hip_ctx *>(cc);
+    if (!c || !c->rays_set) return 0;
+    if (rebuild_shard(c)) return 0;
+    const TileLists t = tile_lists(c);
+    return (size_t)c->n_slots * t.tile_w * t.tile_h;
+}
+
+int vrt_hip_render_shard_device(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *d_shard, void *hip_stream)
+{
+    if (!c || !origin || !d_shard) return VRT_HIP_ERR_INVALID;
+    return render_common(c, origin, pack_flags, d_shard, nullptr, (hipStream_t)hip_stream, true);
+}
+
+int vrt_hip_assemble_shards_device(vrt_hip_ctx *c, const uint32_t *d_gathered, uint32_t *d_image, void *hip_stream)
+{
+    if (!c || !d_gathered || !d_image) return VRT_HIP_ERR_INVALID;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = rebuild_shard(c))) return rc;
+    launch_assemble(d_gathered, d_image, c->slot_tiles.p, c->n_slots * (uint32_t)c->world, tile_lists(c), c->w, c->h,
+                    (hipStream_t)hip_stream);
+    HIPCHK(c, hipGetLastError());
+    return VRT_HIP_OK;
+}
+
+// ---- point queries ------------------------------------------------------------------------------
+static int upload(vrt_hip_ctx *c, DevBuf<float> &b, const float *src, size_t n)
+{
+    HIPCHK(c, b.reserve(n));
+    if (n) HIPCHK(c, hipMemcpy(b.p, src, n * 4, hipMemcpyHostToDevice));
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_transmittance(vrt_hip_ctx *c, const float o[3], const float n[3], const float *s, size_t ns, float *T_out)
+{
+    if (!c || !o || !n || (ns && (!s || !T_out))) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+    DevBuf<float> ds, dT;
+    if ((rc = upload(c, ds, s, ns))) return rc;
+    HIPCHK(c, dT.reserve(ns));
+    launch_transmittance(tables(c), o, n, ds.p, ns, dT.p, c->exp_kind, c->erf_kind, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ns) HIPCHK(c, hipMemcpy(T_out, dT.p, ns * 4, hipMemcpyDeviceToHost));
+    ds.release(); dT.release();
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_transmittance_step(vrt_hip_ctx *c, const float o[3], const float n[3], const float *s, size_t ns, float delta,
+                               float *T_out)
+{
+    if (!c || !o || !n || (ns && (!s || !T_out)) || !(delta > 0.f)) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+    DevBuf<float> ds, dT;
+    if ((rc = upload(c, ds, s, ns))) return rc;
+    HIPCHK(c, dT.reserve(ns));
+    launch_transmittance_step(tables(c), o, n, ds.p, ns, delta, dT.p, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ns) HIPCHK(c, hipMemcpy(T_out, dT.p, ns * 4, hipMemcpyDeviceToHost));
+    ds.release(); dT.release();
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_density(vrt_hip_ctx *c, size_t npts, const float *pts, float *D_out)
+{
+    if (!c || (npts && (!pts || !D_out))) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+    DevBuf<float> dp, dD;
+    if ((rc = upload(c, dp, pts, npts * 3))) return rc;
+    HIPCHK(c, dD.reserve(npts));
+    launch_density(tables(c), dp.p, npts, dD.p, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (npts) HIPCHK(c, hipMemcpy(D_out, dD.p, npts * 4, hipMemcpyDeviceToHost));
+    dp.release(); dD.release();
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_radiance(vrt_hip_ctx *c, size_t nrays, const float *origins, const float *dirs, float *out)
+{
+    if (!c || (nrays && (!origins || !dirs || !out))) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+    DevBuf<float> d_o, d_d;
+    DevBuf<float4> d_out;
+    if ((rc = upload(c, d_o, origins, nrays * 3))) return rc;
+    if ((rc = upload(c, d_d, dirs, nrays * 3))) return rc;
+    HIPCHK(c, d_out.reserve(nrays));
+    launch_radiance(tables(c), d_o.p, d_d.p, nrays, c->iota.p, d_out.p, c->exp_kind, c->erf_kind, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nrays) HIPCHK(c, hipMemcpy(out, d_out.p, nrays * 16, hipMemcpyDeviceToHost));
+    d_o.release(); d_d.release(); d_out.release();
+    return VRT_HIP_OK;
+}
+
+static int eval_common(vrt_hip_ctx *c, bool is_erf, int kind, const float *x, size_t n, float *y)
+{
+    if (!c || (n && (!x || !y))) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf<float> dx, dy;
+    int rc = upload(c, dx, x, n);
+    if (rc) return rc;
+    HIPCHK(c, dy.reserve(n));
+    if (is_erf) launch_eval_erf(kind, dx.p, n, dy.p, c->stream); else launch_eval_exp(kind, dx.p, n, dy.p, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCHK(c, hipMemcpy(y, dy.p, n * 4, hipMemcpyDeviceToHost));
+    dx.release(); dy.release();
+    return VRT_HIP_OK;
+}
+int vrt_hip_eval_erf(vrt_hip_ctx *c, int kind, const float *x, size_t n, float *y) { return eval_common(c, true, kind, x, n, y); }
+int vrt_hip_eval_exp(vrt_hip_ctx *c, int kind, const float *x, size_t n, float *y) { return eval_common(c, false, kind, x, n, y); }
+
+int vrt_hip_enable_stats(vrt_hip_ctx *c, int on)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    c->stats_on = on != 0;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_get_stats(vrt_hip_ctx *c, vrt_hip_stats *out)
+{
+    if (!c || !out) return VRT_HIP_ERR_INVALID;
+    *out = c->last;
+    return VRT_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,80 @@
+// vrt_kernels.h -- launch interface between the C-ABI host code (vrt_hip_api.cpp) and the
+// gfx950 kernels (vrt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vrtk {
+
+constexpr int BLOCK_W = 8;        // one wavefront = one 8x8 pixel block (64 rays)
+constexpr int BLOCK_H = 8;
+constexpr int LIST_CAP = 1024;    // per-block candidate list in LDS (u32 indices)
+
+// Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
+struct SceneTables {
+    const float4 *mu_sig;   // static: (mu.x, mu.y, mu.z, sigma)
+    const float4 *gA;       // per frame: (oc.x, oc.y, oc.z, |oc|^2), oc = mu - origin
+    const float4 *gB;       // static: (r = 1/(sqrt2 sigma), 1/(2 sigma^2), K*sigma*mag, cull_x)
+    const float4 *gC;       // static: albedo rgba
+    const float4 *gD;       // static: (sigma, sigma*mag, mag, 0)
+    uint32_t n;
+};
+
+struct TileLists {
+    const uint32_t *start;    // [ntiles] first entry of tile t in `indices`
+    const uint32_t *count;    // [ntiles]
+    const uint32_t *indices;
+    uint32_t tiles_w, tiles_h;
+    uint32_t tile_w, tile_h;  // pixels: (u64)(width*tw/2.f), rt.h:348-349
+    uint32_t stride;          // tile_w * tiles_w: the reference's row stride, rt.h:364-365
+};
+
+struct RayGen {
+    const float *xs, *ys, *zs; // plane arrays (nullptr => basis mode)
+    float origin[3];
+    float pos[3], right[3], up[3], front[3];
+    float focal, inv_half_w, inv_half_h;
+    uint32_t width, height;
+};
+
+struct RenderTarget {
+    uint32_t *image;          // nullable
+    float4 *radiance;         // nullable
+    int pack_flags;
+    // sharding: tile_map[lt] = global tile id of local tile lt (nullptr = identity);
+    // compact != 0 => image is the tile-major shard buffer [lt][tile_h][tile_w]
+    const uint32_t *tile_map;
+    uint32_t n_local_tiles;
+    int compact;
+    unsigned long long *stats; // nullable: [0]=list entries [1]=tile entries [2]=overflow blocks
+};
+
+void launch_prep_frame(const SceneTables &s, float4 *gA_out, const float origin[3], hipStream_t st);
+void launch_build_static(uint32_t n, const float *mu_x, const float *mu_y, const float *mu_z, const float *ar,
+                         const float *ag, const float *ab, const float *aa, const float *sigma, const float *mag,
+                         float cull_eps, float exp_floor_x, float4 *mu_sig, float4 *gB, float4 *gC, float4 *gD,
+                         hipStream_t st);
+void launch_render(const SceneTables &s, const TileLists &t, const RayGen &r, const RenderTarget &o, int exp_kind,
+                   int erf_kind, hipStream_t st);
+
+// tile binning (rt.cpp:29-69)
+void launch_project(const SceneTables &s, const float view[16], float4 *proj_out, hipStream_t st);
+void launch_bin_tiles(const float4 *proj, uint32_t n, const float *xc, const float *yc, uint32_t tiles_w,
+                      uint32_t tiles_h, float tw, float th, uint32_t *indices, uint32_t *counts, hipStream_t st);
+void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t n_slots,
+                     const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
+void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);
+
+// point queries
+void launch_transmittance(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
+                          float *d_T, int exp_kind, int erf_kind, hipStream_t st);
+void launch_transmittance_step(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
+                               float delta, float *d_T, hipStream_t st);
+void launch_density(const SceneTables &s, const float *d_pts, size_t npts, float *d_D, hipStream_t st);
+// iota: identity index list 0..n-1 on device
+void launch_radiance(const SceneTables &s, const float *d_origins, const float *d_dirs, size_t nrays,
+                     const uint32_t *iota, float4 *d_out, int exp_kind, int erf_kind, hipStream_t st);
+void launch_eval_erf(int kind, const float *x, size_t n, float *y, hipStream_t st);
+void launch_eval_exp(int kind, const float *x, size_t n, float *y, hipStream_t st);
+
+} // namespace vrtk

@@ -1,0 +1,598 @@
+// vrt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the volumetric Gaussian
+// ray tracer.  No MFMA: the path is VALU + quarter-rate transcendental bound (one v_rcp_f32
+// per Abramowitz-Stegun erf term), fed by wave-uniform scalar loads.
+//
+// Reference semantics (paths relative to /root/reference/src):
+//   L(ray) = sum_i albedo_i * sum_{k=-4..0} pdf_i(o + n s_ik) * T(s_ik) * sigma_i,
+//            s_ik = (mu_i - o).n + k sigma_i                               (vrt/rt.h:205-223)
+//   T(s)   = Exp( sum_j sigma_j cbar_j K (Erf(-mubar_j/(sqrt2 sigma_j)) - Erf((s - mubar_j)/(sqrt2 sigma_j))) )
+//            cbar_j = mag_j Exp(-(|oc_j|^2 - mubar_j^2)/(2 sigma_j^2)), K = 1/0.79788456  (vrt/rt.h:102-127)
+// evaluated by the reference with an O(5 N^2) double loop per ray that recomputes cbar_j,
+// mubar_j and Erf(-m_j) for every (i, k, j).  Here, per 8x8 pixel block (= one wavefront,
+// lane = ray):
+//   1. block cull: the block's rays form a cone; a tile Gaussian whose best-case
+//      sigma*mag*exp(-d^2/(2 sigma^2)) over the cone is < cull_eps is dropped
+//      (ballot + mbcnt compaction into an LDS index list).
+//   2. hoist: A_j = K sigma_j cbar_j, m_j = mubar_j r_j, C = sum_j A_j Erf(-m_j) depend on
+//      the ray but not on the sample point, so
+//         T(s_ik) = Exp(C - sum_j A_j Erf(s_ik r_j - m_j)).
+//   3. register blocking: EC emitters x 5 samples = 5*EC running sums per lane stream over
+//      the block's list once; per (ray, j) the (A_j, m_j) pair is recomputed (one exp) and
+//      amortised over the 5*EC erf terms, so nothing per-ray is ever stored.
+//      Gaussian parameters are wave-uniform: they arrive through scalar loads.
+#include "vrt_kernels.h"
+#include "vrt_device_math.h"
+
+namespace vrtk {
+
+// Uniform (scalar) 16-byte load: constant address space + a wave-uniform index => s_load_dwordx4.
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef const vf4 __attribute__((address_space(4))) *cf4ptr;
+__device__ __forceinline__ float4 uload(const float4 *base, uint32_t idx)
+{
+    const vf4 v = ((cf4ptr)(const void *)base)[idx];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t pack_pixel(float r, float g, float b, float a, int flags)
+{
+    uint32_t R, G, B, A;
+    if (flags & VRT_PACK_ROUND) {
+        R = (uint32_t)__float2int_rn(fminf(r, 1.f) * 255.f);
+        G = (uint32_t)__float2int_rn(fminf(g, 1.f) * 255.f);
+        B = (uint32_t)__float2int_rn(fminf(b, 1.f) * 255.f);
+    } else {
+        R = (uint32_t)(fminf(r, 1.f) * 255.f);
+        G = (uint32_t)(fminf(g, 1.f) * 255.f);
+        B = (uint32_t)(fminf(b, 1.f) * 255.f);
+    }
+    if (flags & VRT_ALPHA_COMPUTED) A = ((uint32_t)__float2int_rn(fminf(1.f, a) * 255.f)) << 24;
+    else A = 0xFF000000u;
+    return A | (R << 16) | (G << 8) | B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shading core shared by the image kernel (uniform origin: oc comes from the per-frame table)
+// and the arbitrary-ray kernel (per-lane origin: oc = mu - o).
+// ---------------------------------------------------------------------------------------------
+struct LaneRay { float nx, ny, nz, ox, oy, oz; };
+
+template <bool UNIFORM_ORIGIN>
+__device__ __forceinline__ void ray_gaussian(const SceneTables &S, uint32_t idx, const LaneRay &ray, float &mubar,
+                                             float &d2)
+{
+    if constexpr (UNIFORM_ORIGIN) {
+        const float4 a = uload(S.gA, idx);
+        mubar = __builtin_fmaf(a.z, ray.nz, __builtin_fmaf(a.y, ray.ny, a.x * ray.nx));
+        d2 = __builtin_fmaf(-mubar, mubar, a.w);
+    } else {
+        const float4 m = uload(S.mu_sig, idx);
+        const float cx = m.x - ray.ox, cy = m.y - ray.oy, cz = m.z - ray.oz;
+        mubar = __builtin_fmaf(cz, ray.nz, __builtin_fmaf(cy, ray.ny, cx * ray.nx));
+        const float oc2 = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
+        d2 = __builtin_fmaf(-mubar, mubar, oc2);
+    }
+}
+
+// list: wave-uniform index list (LDS or global, read through a flat pointer); n entries.
+template <int EXP, int ERF, int EC, bool UNIFORM_ORIGIN>
+__device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t *list, uint32_t n, const LaneRay &ray,
+                                           float &Lr, float &Lg, float &Lb, float &La)
+{
+    Lr = Lg = Lb = La = 0.f;
+    if (n == 0) return;
+
+    // pass 0: C = sum_j A_j Erf(-m_j)
+    float Csum = 0.f;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t idx = __builtin_amdgcn_readfirstlane(list[j]);
+        float mubar, d2;
+        ray_gaussian<UNIFORM_ORIGIN>(S, idx, ray, mubar, d2);
+        const float4 b = uload(S.gB, idx);
+        const float A = b.z * vexp<EXP>(-(d2 * b.y));
+        Csum += verf_weighted<ERF>(-(mubar * b.x), A);
+    }
+
+    for (uint32_t i0 = 0; i0 < n; i0 += EC) {
+        // emitter chunk set-up
+        float e_mubar[EC], e_x[EC];
+        float e_sigma[EC]; // wave-uniform
+        uint32_t e_idx[EC];
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            const uint32_t jj = (i0 + e < n) ? (i0 + e) : i0; // pad the tail with a duplicate; masked below
+            e_idx[e] = __builtin_amdgcn_readfirstlane(list[jj]);
+            float d2;
+            ray_gaussian<UNIFORM_ORIGIN>(S, e_idx[e], ray, e_mubar[e], d2);
+            const float4 b = uload(S.gB, e_idx[e]);
+            e_x[e] = d2 * b.y;
+            e_sigma[e] = uload(S.gD, e_idx[e]).x;
+        }
+        float acc[EC][5];
+#pragma unroll
+        for (int e = 0; e < EC; ++e)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[e][k] = 0.f;
+
+        // absorber stream: 5*EC erf terms per (ray, j)
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t idx = __builtin_amdgcn_readfirstlane(list[j]);
+            float mubar, d2;
+            ray_gaussian<UNIFORM_ORIGIN>(S, idx, ray, mubar, d2);
+            const float4 b = uload(S.gB, idx);
+            const float A = b.z * vexp<EXP>(-(d2 * b.y));
+            const float m = mubar * b.x;
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+                const float base = __builtin_fmaf(e_mubar[e], b.x, -m); // (mubar_i - mubar_j) r_j
+                const float step = e_sigma[e] * b.x;                     // sigma_i r_j
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float x = __builtin_fmaf((float)(k - 4), step, base);
+                    acc[e][k] += verf_weighted<ERF>(x, A);
+                }
+            }
+        }
+
+        // emission: pdf_i(o + n s_ik) = mag_i Exp(-(d2_i + k^2 sigma_i^2)/(2 sigma_i^2))  (types.h:204-208)
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            if (i0 + e < n) {
+                const float q = uload(S.gD, e_idx[e]).y; // sigma * mag
+                float inner = 0.f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float kk = (float)((k - 4) * (k - 4)) * 0.5f;
+                    const float T = vexp<EXP>(Csum - acc[e][k]);
+                    inner = __builtin_fmaf(q * vexp<EXP>(-(e_x[e] + kk)), T, inner);
+                }
+                const float4 alb = uload(S.gC, e_idx[e]);
+                Lr = __builtin_fmaf(alb.x, inner, Lr);
+                Lg = __builtin_fmaf(alb.y, inner, Lg);
+                Lb = __builtin_fmaf(alb.z, inner, Lb);
+                La = __builtin_fmaf(alb.w, inner, La);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Image kernel: one wavefront per 8x8 pixel block of one reference tile.
+// ---------------------------------------------------------------------------------------------
+template <int EXP, int ERF, int EC>
+__global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, RayGen R, RenderTarget O,
+                                                     uint32_t blocks_x, uint32_t blocks_y)
+{
+    __shared__ uint32_t s_list[LIST_CAP];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t bpt = blocks_x * blocks_y;
+    const uint32_t lt = blockIdx.x / bpt, b = blockIdx.x % bpt;
+    const uint32_t t = O.tile_map ? O.tile_map[lt] : lt;
+    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+    const uint32_t bxi = b % blocks_x, byi = b / blocks_x;
+
+    // ---- this lane's pixel and ray (rt.h:362-371) ----
+    const uint32_t pxt = bxi * BLOCK_W + (lane & 7), pyt = byi * BLOCK_H + (lane >> 3);
+    bool valid = pxt < T.tile_w && pyt < T.tile_h;
+    const uint32_t pxc = min(pxt, T.tile_w - 1), pyc = min(pyt, T.tile_h - 1);
+    const uint64_t npix = (uint64_t)R.width * R.height;
+    uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
+    if (pix >= npix) { valid = false; pix = npix - 1; }
+
+    float px, py, pz;
+    if (R.xs) {
+        px = R.xs[pix]; py = R.ys[pix]; pz = R.zs[pix];
+    } else {
+        // closed form of camera.cpp:52,60-69: plane = pos + x right + y up - focal front
+        const uint32_t jcol = (uint32_t)(pix % R.width), irow = (uint32_t)(pix / R.width);
+        const float x = -1.f + (float)jcol * R.inv_half_w;
+        const float y = -1.f + (float)irow * R.inv_half_h;
+        px = R.pos[0] + x * R.right[0] + y * R.up[0] - R.focal * R.front[0];
+        py = R.pos[1] + x * R.right[1] + y * R.up[1] - R.focal * R.front[1];
+        pz = R.pos[2] + x * R.right[2] + y * R.up[2] - R.focal * R.front[2];
+    }
+    LaneRay ray;
+    ray.ox = R.origin[0]; ray.oy = R.origin[1]; ray.oz = R.origin[2];
+    {
+        const float dx = px - ray.ox, dy = py - ray.oy, dz = pz - ray.oz;
+        const float norm = sqrtf(dx * dx + dy * dy + dz * dz);
+        ray.nx = dx / norm; ray.ny = dy / norm; ray.nz = dz / norm;
+    }
+
+    // ---- block cone: axis c and the largest angle of any lane's ray to it ----
+    float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
+    float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
+    float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
+    {
+        const float inv = 1.f / sqrtf(cx * cx + cy * cy + cz * cz);
+        cx *= inv; cy *= inv; cz *= inv;
+    }
+    float cos_t = fminf(wave_min(ray.nx * cx + ray.ny * cy + ray.nz * cz), 1.f);
+    float sin_t = sqrtf(fmaxf(0.f, 1.f - cos_t * cos_t));
+    cos_t = cos_t * 0.9999f;            // conservative: never over-estimate the distance to the cone
+    sin_t = sin_t * 1.0001f + 1e-6f;
+
+    // ---- block cull over the reference tile's list (ballot compaction, order preserving) ----
+    const uint32_t n_tile = T.count[t];
+    const uint32_t *tile_list = T.indices + T.start[t];
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < n_tile; base += 64) {
+        const uint32_t k = base + lane;
+        bool keep = false;
+        uint32_t idx = 0;
+        if (k < n_tile) {
+            idx = tile_list[k];
+            const float4 a = S.gA[idx];
+            const float4 bq = S.gB[idx];
+            const float tc = a.x * cx + a.y * cy + a.z * cz;
+            const float dperp = sqrtf(fmaxf(0.f, a.w - tc * tc));
+            const float dmin = fmaxf(0.f, dperp * cos_t - fabsf(tc) * sin_t);
+            const float xmin = dmin * dmin * bq.y;
+            keep = !(xmin * 0.999f - 1e-3f > bq.w);
+        }
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        if (keep && pos < LIST_CAP) s_list[pos] = idx;
+        cnt += (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+    const bool overflow = cnt > LIST_CAP;
+    const uint32_t *list = overflow ? tile_list : (const uint32_t *)s_list;
+    const uint32_t n = overflow ? n_tile : cnt;
+    if (O.stats && lane == 0) {
+        atomicAdd(&O.stats[0], (unsigned long long)n);
+        atomicAdd(&O.stats[1], (unsigned long long)n_tile);
+        if (overflow) atomicAdd(&O.stats[2], 1ull);
+    }
+
+    float Lr, Lg, Lb, La;
+    shade_list<EXP, ERF, EC, true>(S, list, n, ray, Lr, Lg, Lb, La);
+
+    if (valid) {
+        uint64_t out = pix;
+        if (O.compact) out = ((uint64_t)lt * T.tile_h + pyt) * T.tile_w + pxt;
+        if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
+        if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
+    }
+}
+
+template <int EXP, int ERF>
+static void launch_render_t(const SceneTables &s, const TileLists &t, const RayGen &r, const RenderTarget &o,
+                            hipStream_t st)
+{
+    const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
+    const uint64_t nblocks = (uint64_t)o.n_local_tiles * bx * by;
+    if (nblocks == 0) return;
+    hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3((uint32_t)nblocks), dim3(64), 0, st, s, t, r, o, bx, by);
+}
+
+#define VRT_DISPATCH_EXP_ERF(FN, ...)                                                              \
+    switch (exp_kind * 8 + erf_kind) {                                                             \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM>(__VA_ARGS__); break;      \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS>(__VA_ARGS__); break;          \
+    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM>(__VA_ARGS__); break;        \
+    case VRT_EXP_VCL * 8 + VRT_ERF_AS: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;            \
+    case VRT_EXP_FAST * 8 + VRT_ERF_AS: FN<VRT_EXP_FAST, VRT_ERF_AS>(__VA_ARGS__); break;          \
+    case VRT_EXP_SPLINE * 8 + VRT_ERF_AS: FN<VRT_EXP_SPLINE, VRT_ERF_AS>(__VA_ARGS__); break;      \
+    case VRT_EXP_VCL * 8 + VRT_ERF_SPLINE: FN<VRT_EXP_VCL, VRT_ERF_SPLINE>(__VA_ARGS__); break;    \
+    case VRT_EXP_VCL * 8 + VRT_ERF_SPLINE_MIRROR: FN<VRT_EXP_VCL, VRT_ERF_SPLINE_MIRROR>(__VA_ARGS__); break; \
+    case VRT_EXP_VCL * 8 + VRT_ERF_TAYLOR: FN<VRT_EXP_VCL, VRT_ERF_TAYLOR>(__VA_ARGS__); break;    \
+    default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
+    }
+
+void launch_render(const SceneTables &s, const TileLists &t, const RayGen &r, const RenderTarget &o, int exp_kind,
+                   int erf_kind, hipStream_t st)
+{
+    VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, r, o, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene tables
+// ---------------------------------------------------------------------------------------------
+__global__ void build_static_kernel(uint32_t n, const float *mu_x, const float *mu_y, const float *mu_z,
+                                    const float *ar, const float *ag, const float *ab, const float *aa,
+                                    const float *sigma, const float *mag, float cull_eps, float exp_floor_x,
+                                    float4 *mu_sig, float4 *gB, float4 *gC, float4 *gD)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = sigma[i], m = mag[i];
+    mu_sig[i] = make_float4(mu_x[i], mu_y[i], mu_z[i], s);
+    const float q = s * m;
+    // cull_x: drop when d^2/(2 sigma^2) > ln(|q|/eps); never keep what Exp flushes to zero anyway
+    float cull_x = exp_floor_x;
+    if (q == 0.f) cull_x = -INFINITY;
+    else if (cull_eps > 0.f) cull_x = fminf(cull_x, logf(fabsf(q) / cull_eps));
+    gB[i] = make_float4(1.f / (SQRT_2 * s), 1.f / (2.f * s * s), q * INV_SQRT_2_PI, cull_x);
+    gC[i] = make_float4(ar[i], ag[i], ab[i], aa ? aa[i] : 1.f);
+    gD[i] = make_float4(s, q, m, 0.f);
+}
+
+void launch_build_static(uint32_t n, const float *mu_x, const float *mu_y, const float *mu_z, const float *ar,
+                         const float *ag, const float *ab, const float *aa, const float *sigma, const float *mag,
+                         float cull_eps, float exp_floor_x, float4 *mu_sig, float4 *gB, float4 *gC, float4 *gD,
+                         hipStream_t st)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(build_static_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, mu_x, mu_y, mu_z, ar, ag, ab,
+                       aa, sigma, mag, cull_eps, exp_floor_x, mu_sig, gB, gC, gD);
+}
+
+__global__ void prep_frame_kernel(uint32_t n, const float4 *mu_sig, float4 *gA, float ox, float oy, float oz)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 m = mu_sig[i];
+    const float cx = m.x - ox, cy = m.y - oy, cz = m.z - oz;
+    gA[i] = make_float4(cx, cy, cz, cx * cx + cy * cy + cz * cz);
+}
+
+void launch_prep_frame(const SceneTables &s, float4 *gA_out, const float origin[3], hipStream_t st)
+{
+    if (!s.n) return;
+    hipLaunchKernelGGL(prep_frame_kernel, dim3((s.n + 255) / 256), dim3(256), 0, st, s.n, s.mu_sig, gA_out, origin[0],
+                       origin[1], origin[2]);
+}
+
+__global__ void iota_kernel(uint32_t *p, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+void launch_iota(uint32_t *p, uint32_t n, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile binning: vrt/rt.cpp:29-69 on device.  Arithmetic is kept unfused and in the reference's
+// order so that inclusion decisions (a "<=" on floats) reproduce the host algorithm.
+// ---------------------------------------------------------------------------------------------
+struct Mat4 { float m[16]; };
+
+__global__ void project_kernel(uint32_t n, const float4 *mu_sig, Mat4 V, float4 *proj)
+{
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 g = mu_sig[i];
+    // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
+    const float x = (V.m[0] * g.x + V.m[4] * g.y) + (V.m[8] * g.z + V.m[12] * 1.f);
+    const float y = (V.m[1] * g.x + V.m[5] * g.y) + (V.m[9] * g.z + V.m[13] * 1.f);
+    const float z = (V.m[2] * g.x + V.m[6] * g.y) + (V.m[10] * g.z + V.m[14] * 1.f);
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(z < 1.f)) {                       // rt.cpp:38
+        const float sig = g.w / z;          // rt.cpp:40
+        if (!(sig < 1e-5f)) out = make_float4(x / z, y / z, sig, 1.f); // rt.cpp:39-41
+    }
+    proj[i] = out;
+}
+
+void launch_project(const SceneTables &s, const float view[16], float4 *proj_out, hipStream_t st)
+{
+    if (!s.n) return;
+    Mat4 V;
+    for (int i = 0; i < 16; ++i) V.m[i] = view[i];
+    hipLaunchKernelGGL(project_kernel, dim3((s.n + 255) / 256), dim3(256), 0, st, s.n, s.mu_sig, V, proj_out);
+}
+
+// one wavefront per tile; list of tile t lives at indices[t*n .. t*n + counts[t])
+__global__ __launch_bounds__(64) void bin_tiles_kernel(const float4 *proj, uint32_t n, const float *xc, const float *yc,
+                                                        uint32_t tiles_w, float tw, float th, uint32_t *indices,
+                                                        uint32_t *counts)
+{
+#pragma clang fp contract(off)
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    const float x = xc[t % tiles_w], y = yc[t / tiles_w];
+    const float ax = fabsf(x) + tw / 2, ay = fabsf(y) + th / 2; // rt.cpp:58-59 (left-to-right sums)
+    uint32_t *out = indices + (size_t)t * n;
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        bool keep = false;
+        if (i < n) {
+            const float4 p = proj[i];
+            if (p.w != 0.f) {
+                const float dx = fabsf(x - p.x), dy = fabsf(y - p.y);
+                const float s33 = 3.3f * p.z;
+                keep = (dx <= ax + s33) && (dy <= ay + s33);
+            }
+        }
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        if (keep) out[pos] = i;
+        cnt += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) counts[t] = cnt;
+}
+
+void launch_bin_tiles(const float4 *proj, uint32_t n, const float *xc, const float *yc, uint32_t tiles_w,
+                      uint32_t tiles_h, float tw, float th, uint32_t *indices, uint32_t *counts, hipStream_t st)
+{
+    if (tiles_w * tiles_h == 0) return;
+    hipLaunchKernelGGL(bin_tiles_kernel, dim3(tiles_w * tiles_h), dim3(64), 0, st, proj, n, xc, yc, tiles_w, tw, th,
+                       indices, counts);
+}
+
+// scatter rank-major shard buffers [slot][tile_h][tile_w] into the raster image (rt.h:388-399)
+__global__ void assemble_kernel(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, TileLists T,
+                                uint32_t width, uint32_t height)
+{
+    const uint32_t slot = blockIdx.y;
+    const uint32_t t = tile_of_slot[slot];
+    if (t == 0xFFFFFFFFu) return;
+    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+    const uint32_t per_tile = T.tile_w * T.tile_h;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < per_tile; p += gridDim.x * blockDim.x) {
+        const uint32_t lx = p % T.tile_w, ly = p / T.tile_w;
+        const uint64_t pix = (uint64_t)(tx * T.tile_w + lx) + (uint64_t)T.stride * (ty * T.tile_h + ly);
+        if (pix < (uint64_t)width * height) image[pix] = gathered[(size_t)slot * per_tile + p];
+    }
+}
+
+void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t n_slots,
+                     const TileLists &t, uint32_t width, uint32_t height, hipStream_t st)
+{
+    if (!n_slots) return;
+    const uint32_t per_tile = t.tile_w * t.tile_h;
+    const uint32_t gx = min((per_tile + 255u) / 256u, 64u);
+    hipLaunchKernelGGL(assemble_kernel, dim3(gx ? gx : 1, n_slots), dim3(256), 0, st, gathered, image, tile_of_slot, t,
+                       width, height);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point queries (API parity with rt.h:32-54, rt.cpp:8-27, rt.h:146-223); not performance paths.
+// ---------------------------------------------------------------------------------------------
+template <int EXP, int ERF>
+__global__ void transmittance_kernel(SceneTables S, float ox, float oy, float oz, float nx, float ny, float nz,
+                                     const float *s_in, size_t ns, float *T_out)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const float s = s_in[k];
+    float T = 0.f;
+    for (uint32_t q = 0; q < S.n; ++q) { // rt.h:36-52, same operation order
+        const float4 g = S.mu_sig[q];
+        const float mag = S.gD[q].z;
+        const float cx = g.x - ox, cy = g.y - oy, cz = g.z - oz;
+        const float mu_bar = cx * nx + cy * ny + cz * nz;
+        const float oc_sq = cx * cx + cy * cy + cz * cz;
+        const float inv_2_sigma2 = 1.f / (2.f * g.w * g.w);
+        const float c_bar = mag * vexp<EXP>(-((oc_sq - mu_bar * mu_bar) * inv_2_sigma2));
+        const float sqrt_2_sig = SQRT_2 * g.w;
+        const float mu_bar_n = mu_bar / sqrt_2_sig;
+        const float s_n = s / sqrt_2_sig;
+        T += g.w * c_bar * INV_SQRT_2_PI * (verf<ERF>(-mu_bar_n) - verf<ERF>(s_n - mu_bar_n));
+    }
+    T_out[k] = vexp<EXP>(T);
+}
+template <int EXP, int ERF>
+static void launch_transmittance_t(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
+                                   float *d_T, hipStream_t st)
+{
+    hipLaunchKernelGGL((transmittance_kernel<EXP, ERF>), dim3((uint32_t)((ns + 63) / 64)), dim3(64), 0, st, s, o[0],
+                       o[1], o[2], n[0], n[1], n[2], d_s, ns, d_T);
+}
+void launch_transmittance(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
+                          float *d_T, int exp_kind, int erf_kind, hipStream_t st)
+{
+    if (!ns) return;
+    VRT_DISPATCH_EXP_ERF(launch_transmittance_t, s, o, n, d_s, ns, d_T, st);
+}
+
+// rt.cpp:8-17: Riemann sum with step delta, fast_exp of the negated sum
+__global__ void transmittance_step_kernel(SceneTables S, float ox, float oy, float oz, float nx, float ny, float nz,
+                                          const float *s_in, size_t ns, float delta, float *T_out)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const float s = s_in[k];
+    float T = 0.f;
+    for (float t = 0; t <= s; t += delta)
+        for (uint32_t q = 0; q < S.n; ++q) {
+            const float4 g = S.mu_sig[q];
+            const float dx = ox + nx * t - g.x, dy = oy + ny * t - g.y, dz = oz + nz * t - g.z;
+            T += delta * (S.gD[q].z * exp_accurate(-(dx * dx + dy * dy + dz * dz) / (2 * g.w * g.w)));
+        }
+    T_out[k] = exp_fast(-T);
+}
+void launch_transmittance_step(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
+                               float delta, float *d_T, hipStream_t st)
+{
+    if (!ns) return;
+    hipLaunchKernelGGL(transmittance_step_kernel, dim3((uint32_t)((ns + 63) / 64)), dim3(64), 0, st, s, o[0], o[1],
+                       o[2], n[0], n[1], n[2], d_s, ns, delta, d_T);
+}
+
+// rt.cpp:19-27
+__global__ void density_kernel(SceneTables S, const float *pts, size_t npts, float *D)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= npts) return;
+    const float x = pts[3 * k], y = pts[3 * k + 1], z = pts[3 * k + 2];
+    float acc = 0.f;
+    for (uint32_t q = 0; q < S.n; ++q) {
+        const float4 g = S.mu_sig[q];
+        const float dx = x - g.x, dy = y - g.y, dz = z - g.z;
+        acc += S.gD[q].z * exp_accurate(-(dx * dx + dy * dy + dz * dz) / (2 * g.w * g.w));
+    }
+    D[k] = acc;
+}
+void launch_density(const SceneTables &s, const float *d_pts, size_t npts, float *d_D, hipStream_t st)
+{
+    if (!npts) return;
+    hipLaunchKernelGGL(density_kernel, dim3((uint32_t)((npts + 63) / 64)), dim3(64), 0, st, s, d_pts, npts, d_D);
+}
+
+// arbitrary rays: lane = ray, every Gaussian of the scene, per-lane origin
+template <int EXP, int ERF>
+__global__ __launch_bounds__(64) void radiance_kernel(SceneTables S, const float *origins, const float *dirs,
+                                                       size_t nrays, const uint32_t *iota, float4 *out)
+{
+    const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t rc = r < nrays ? r : nrays - 1;
+    LaneRay ray;
+    ray.ox = origins[3 * rc]; ray.oy = origins[3 * rc + 1]; ray.oz = origins[3 * rc + 2];
+    ray.nx = dirs[3 * rc]; ray.ny = dirs[3 * rc + 1]; ray.nz = dirs[3 * rc + 2];
+    float Lr, Lg, Lb, La;
+    shade_list<EXP, ERF, 4, false>(S, iota, S.n, ray, Lr, Lg, Lb, La);
+    if (r < nrays) out[r] = make_float4(Lr, Lg, Lb, La);
+}
+template <int EXP, int ERF>
+static void launch_radiance_t(const SceneTables &s, const float *d_origins, const float *d_dirs, size_t nrays,
+                              const uint32_t *iota, float4 *d_out, hipStream_t st)
+{
+    hipLaunchKernelGGL((radiance_kernel<EXP, ERF>), dim3((uint32_t)((nrays + 63) / 64)), dim3(64), 0, st, s, d_origins,
+                       d_dirs, nrays, iota, d_out);
+}
+void launch_radiance(const SceneTables &s, const float *d_origins, const float *d_dirs, size_t nrays,
+                     const uint32_t *iota, float4 *d_out, int exp_kind, int erf_kind, hipStream_t st)
+{
+    if (!nrays) return;
+    VRT_DISPATCH_EXP_ERF(launch_radiance_t, s, d_origins, d_dirs, nrays, iota, d_out, st);
+}
+
+template <int K>
+__global__ void eval_erf_kernel(const float *x, size_t n, float *y)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = verf<K>(x[i]);
+}
+template <int K>
+__global__ void eval_exp_kernel(const float *x, size_t n, float *y)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = vexp<K>(x[i]);
+}
+void launch_eval_erf(int kind, const float *x, size_t n, float *y, hipStream_t st)
+{
+    if (!n) return;
+    const dim3 g((uint32_t)((n + 255) / 256)), b(256);
+    switch (kind) {
+    case VRT_ERF_AS: hipLaunchKernelGGL(eval_erf_kernel<VRT_ERF_AS>, g, b, 0, st, x, n, y); break;
+    case VRT_ERF_SPLINE: hipLaunchKernelGGL(eval_erf_kernel<VRT_ERF_SPLINE>, g, b, 0, st, x, n, y); break;
+    case VRT_ERF_SPLINE_MIRROR: hipLaunchKernelGGL(eval_erf_kernel<VRT_ERF_SPLINE_MIRROR>, g, b, 0, st, x, n, y); break;
+    case VRT_ERF_TAYLOR: hipLaunchKernelGGL(eval_erf_kernel<VRT_ERF_TAYLOR>, g, b, 0, st, x, n, y); break;
+    default: hipLaunchKernelGGL(eval_erf_kernel<VRT_ERF_LIBM>, g, b, 0, st, x, n, y); break;
+    }
+}
+void launch_eval_exp(int kind, const float *x, size_t n, float *y, hipStream_t st)
+{
+    if (!n) return;
+    const dim3 g((uint32_t)((n + 255) / 256)), b(256);
+    switch (kind) {
+    case VRT_EXP_VCL: hipLaunchKernelGGL(eval_exp_kernel<VRT_EXP_VCL>, g, b, 0, st, x, n, y); break;
+    case VRT_EXP_FAST: hipLaunchKernelGGL(eval_exp_kernel<VRT_EXP_FAST>, g, b, 0, st, x, n, y); break;
+    case VRT_EXP_SPLINE: hipLaunchKernelGGL(eval_exp_kernel<VRT_EXP_SPLINE>, g, b, 0, st, x, n, y); break;
+    default: hipLaunchKernelGGL(eval_exp_kernel<VRT_EXP_LIBM>, g, b, 0, st, x, n, y); break;
+    }
+}
+
+} // namespace vrtk
