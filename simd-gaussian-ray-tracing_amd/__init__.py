@@ -83,6 +83,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise VrtHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950)")
+        try:
+            # PyTorch ships its own libamdhip64; load it first so the process has ONE HIP runtime
+            # (torch is the plumbing for device buffers / streams / RCCL in tests and bench.py)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -115,9 +115,13 @@ __device__ __forceinline__ float as_erf_weighted(float x, float A)
 }
 __device__ __forceinline__ float erf_as(float x)
 {
-    // approx.cpp:5 SIGN(x): +1 for x >= 0 (incl. -0), -1 for x < 0
-    const float v = as_erf_weighted(x, 1.0f);
-    return (x == 0.f) ? __builtin_fabsf(v) : v;
+    const float t = __builtin_fabsf(x);
+    float p = __builtin_fmaf(0.078108f, t, 0.000972f);
+    p = __builtin_fmaf(p, t, 0.230389f);
+    p = __builtin_fmaf(p, t, 0.278393f);
+    p = __builtin_fmaf(p, t, 1.0f);
+    const float p2 = p * p;
+    return __builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p2 * p2), x);
 }
 
 // approx.cpp:9-24 spline_erf

@@ -13,9 +13,9 @@
 //   1. block cull: the block's rays form a cone; a tile Gaussian whose best-case
 //      sigma*mag*exp(-d^2/(2 sigma^2)) over the cone is < cull_eps is dropped
 //      (ballot + mbcnt compaction into an LDS index list).
-//   2. hoist: A_j = K sigma_j cbar_j, m_j = mubar_j r_j, C = sum_j A_j Erf(-m_j) depend on
-//      the ray but not on the sample point, so
-//         T(s_ik) = Exp(C - sum_j A_j Erf(s_ik r_j - m_j)).
+//   2. hoist: A_j = K sigma_j cbar_j, m_j = mubar_j r_j and E_j = Erf(-m_j) depend on the ray but
+//      not on the sample point, so
+//         T(s_ik) = Exp(sum_j A_j (E_j - Erf(s_ik r_j - m_j))).
 //   3. register blocking: EC emitters x 5 samples = 5*EC running sums per lane stream over
 //      the block's list once; per (ray, j) the (A_j, m_j) pair is recomputed (one exp) and
 //      amortised over the 5*EC erf terms, so nothing per-ray is ever stored.
@@ -64,20 +64,46 @@ __device__ __forceinline__ uint32_t pack_pixel(float r, float g, float b, float 
 // ---------------------------------------------------------------------------------------------
 struct LaneRay { float nx, ny, nz, ox, oy, oz; };
 
+// The reference forms cbar_j from |oc|^2 - mubar^2 (rt.h:110-116): a difference of two numbers of size
+// |oc|^2 ~ 25 whose result is ~sigma^2, so its fp32 rounding noise (a few 1e-6 absolute, times
+// 1/(2 sigma^2) up to ~1e4) is far above 1 ulp of the result and shows up in the image at the
+// 1e-4 level for small sigma.  Parity therefore needs the reference's operations in the reference's
+// order, unfused -- not a "more accurate" formula.  These helpers pin that order (vec4f_t::dot,
+// types.h:54-57: ((x*x' + y*y') + z*z') + w*w', the w terms being exactly 0 here).
+__device__ __forceinline__ float dot3_ref(float ax, float ay, float az, float bx, float by, float bz)
+{
+#pragma clang fp contract(off)
+    return ((ax * bx + ay * by) + az * bz);
+}
+__device__ __forceinline__ float sub_ref(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float mul_ref(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float madd_ref(float a, float b, float c) // a*b + c, two roundings
+{
+#pragma clang fp contract(off)
+    return a * b + c;
+}
+
 template <bool UNIFORM_ORIGIN>
 __device__ __forceinline__ void ray_gaussian(const SceneTables &S, uint32_t idx, const LaneRay &ray, float &mubar,
                                              float &d2)
 {
     if constexpr (UNIFORM_ORIGIN) {
-        const float4 a = uload(S.gA, idx);
-        mubar = __builtin_fmaf(a.z, ray.nz, __builtin_fmaf(a.y, ray.ny, a.x * ray.nx));
-        d2 = __builtin_fmaf(-mubar, mubar, a.w);
+        const float4 a = uload(S.gA, idx); // (oc, |oc|^2) from prep_frame_kernel, reference order
+        mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+        d2 = sub_ref(a.w, mul_ref(mubar, mubar));
     } else {
         const float4 m = uload(S.mu_sig, idx);
         const float cx = m.x - ray.ox, cy = m.y - ray.oy, cz = m.z - ray.oz;
-        mubar = __builtin_fmaf(cz, ray.nz, __builtin_fmaf(cy, ray.ny, cx * ray.nx));
-        const float oc2 = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
-        d2 = __builtin_fmaf(-mubar, mubar, oc2);
+        mubar = dot3_ref(cx, cy, cz, ray.nx, ray.ny, ray.nz);
+        d2 = sub_ref(dot3_ref(cx, cy, cz, cx, cy, cz), mul_ref(mubar, mubar));
     }
 }
 
@@ -89,20 +115,9 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
     Lr = Lg = Lb = La = 0.f;
     if (n == 0) return;
 
-    // pass 0: C = sum_j A_j Erf(-m_j)
-    float Csum = 0.f;
-    for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t idx = __builtin_amdgcn_readfirstlane(list[j]);
-        float mubar, d2;
-        ray_gaussian<UNIFORM_ORIGIN>(S, idx, ray, mubar, d2);
-        const float4 b = uload(S.gB, idx);
-        const float A = b.z * vexp<EXP>(-(d2 * b.y));
-        Csum += verf_weighted<ERF>(-(mubar * b.x), A);
-    }
-
     for (uint32_t i0 = 0; i0 < n; i0 += EC) {
         // emitter chunk set-up
-        float e_mubar[EC], e_x[EC];
+        float e_mubar[EC];
         float e_sigma[EC]; // wave-uniform
         uint32_t e_idx[EC];
 #pragma unroll
@@ -111,8 +126,6 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
             e_idx[e] = __builtin_amdgcn_readfirstlane(list[jj]);
             float d2;
             ray_gaussian<UNIFORM_ORIGIN>(S, e_idx[e], ray, e_mubar[e], d2);
-            const float4 b = uload(S.gB, e_idx[e]);
-            e_x[e] = d2 * b.y;
             e_sigma[e] = uload(S.gD, e_idx[e]).x;
         }
         float acc[EC][5];
@@ -129,6 +142,7 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
             const float4 b = uload(S.gB, idx);
             const float A = b.z * vexp<EXP>(-(d2 * b.y));
             const float m = mubar * b.x;
+            const float E = verf<ERF>(-m); // Erf(-mubar_j / (sqrt2 sigma_j)), rt.h:122
 #pragma unroll
             for (int e = 0; e < EC; ++e) {
                 const float base = __builtin_fmaf(e_mubar[e], b.x, -m); // (mubar_i - mubar_j) r_j
@@ -136,22 +150,33 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const float x = __builtin_fmaf((float)(k - 4), step, base);
-                    acc[e][k] += verf_weighted<ERF>(x, A);
+                    // rt.h:124: T += sigma cbar K (erf1 - erf2).  Summing the per-term DIFFERENCE like the
+                    // reference (not C - sum A erf2) keeps the running sum small in optically thick scenes,
+                    // where saturated pairs cancel exactly.
+                    acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
                 }
             }
         }
 
-        // emission: pdf_i(o + n s_ik) = mag_i Exp(-(d2_i + k^2 sigma_i^2)/(2 sigma_i^2))  (types.h:204-208)
+        // emission: pdf_i(o + n s_ik) = mag_i Exp(-|o + n s_ik - mu_i|^2 / (2 sigma_i^2)), formed from the
+        // sample POINT like the reference (rt.h:216-218, types.h:204-208) -- not from d2_i + k^2 sigma^2,
+        // whose |oc|^2 - mubar^2 carries the cancellation noise described above.
 #pragma unroll
         for (int e = 0; e < EC; ++e) {
             if (i0 + e < n) {
+                const float4 ms = uload(S.mu_sig, e_idx[e]);
+                const float4 bq = uload(S.gB, e_idx[e]);
                 const float q = uload(S.gD, e_idx[e]).y; // sigma * mag
                 float inner = 0.f;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
-                    const float kk = (float)((k - 4) * (k - 4)) * 0.5f;
-                    const float T = vexp<EXP>(Csum - acc[e][k]);
-                    inner = __builtin_fmaf(q * vexp<EXP>(-(e_x[e] + kk)), T, inner);
+                    const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[e]);      // s = mubar_i + k sigma_i
+                    const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);     // (o + n s) - mu
+                    const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
+                    const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
+                    const float dd = dot3_ref(px, py, pz, px, py, pz);
+                    const float T = vexp<EXP>(acc[e][k]);
+                    inner = __builtin_fmaf(q * vexp<EXP>(-(dd * bq.y)), T, inner);
                 }
                 const float4 alb = uload(S.gC, e_idx[e]);
                 Lr = __builtin_fmaf(alb.x, inner, Lr);
@@ -201,8 +226,11 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     LaneRay ray;
     ray.ox = R.origin[0]; ray.oy = R.origin[1]; ray.oz = R.origin[2];
     {
+        // rt.h:366-371 + vec4f_t::normalize (types.h:75-82): IEEE sqrt and divides, unfused dot
         const float dx = px - ray.ox, dy = py - ray.oy, dz = pz - ray.oz;
-        const float norm = sqrtf(dx * dx + dy * dy + dz * dz);
+        // (sqrtf and '/' are correctly rounded in HIP's default mode; __fsqrt_rn is NOT -- it maps to the
+        // 1-ulp v_sqrt_f32, and a 1-ulp change of n is amplified by the cancellation noise above)
+        const float norm = __builtin_sqrtf(dot3_ref(dx, dy, dz, dx, dy, dz));
         ray.nx = dx / norm; ray.ny = dy / norm; ray.nz = dz / norm;
     }
 
@@ -331,7 +359,7 @@ __global__ void prep_frame_kernel(uint32_t n, const float4 *mu_sig, float4 *gA, 
     if (i >= n) return;
     const float4 m = mu_sig[i];
     const float cx = m.x - ox, cy = m.y - oy, cz = m.z - oz;
-    gA[i] = make_float4(cx, cy, cz, cx * cx + cy * cy + cz * cz);
+    gA[i] = make_float4(cx, cy, cz, dot3_ref(cx, cy, cz, cx, cy, cz)); // vec4f_t::sqnorm order (types.h:69-72)
 }
 
 void launch_prep_frame(const SceneTables &s, float4 *gA_out, const float origin[3], hipStream_t st)

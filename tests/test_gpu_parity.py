@@ -184,7 +184,12 @@ def test_device_erf_exp_against_reference_tables(pkg, oracle, renderer):
     v = renderer.eval_exp(pkg.EXP_VCL, xe)
     assert (np.abs(v - gold["vcl_exp"]) <= 2.5e-7 * np.abs(gold["vcl_exp"])).all()   # ~2 ulp
     assert (renderer.eval_exp(pkg.EXP_VCL, np.array([-87.4, -100.0], np.float32)) == 0).all()
-    np.testing.assert_array_equal(renderer.eval_exp(pkg.EXP_FAST, xe), gold["fast_exp"])
+    # fast_exp builds the float's bit pattern from a*x+b, a cancelling sum of two ~1e9 terms: the reference binary
+    # (-ffast-math => fused multiply-add) and the unfused source semantics differ by the product's rounding
+    # (<= 64 integer steps = 8e-6 relative); the device follows the unfused source, bit-exact with the oracle
+    fe = renderer.eval_exp(pkg.EXP_FAST, xe)
+    assert (np.abs(fe - gold["fast_exp"]) <= 1e-5 * np.abs(gold["fast_exp"])).all()
+    np.testing.assert_array_equal(fe, oracle.map_scalar("oracle_fast_exp", xe))
     assert np.abs(renderer.eval_exp(pkg.EXP_SPLINE, xe) - gold["spline_exp"]).max() <= 1e-7
 
 
@@ -241,7 +246,12 @@ def test_alternate_approximations_render(pkg, oracle, renderer):
     cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h)
     for ek, rk, tol in [(pkg.EXP_LIBM, pkg.ERF_LIBM, 2e-5), (pkg.EXP_FAST, pkg.ERF_AS, 2e-5),
                         (pkg.EXP_SPLINE, pkg.ERF_AS, 2e-5), (pkg.EXP_VCL, pkg.ERF_SPLINE, 2e-5),
-                        (pkg.EXP_VCL, pkg.ERF_SPLINE_MIRROR, 2e-5), (pkg.EXP_VCL, pkg.ERF_TAYLOR, 2e-5)]:
+                        # spline_erf_mirror jumps by 0.107 at x = 0 (approx.cpp:45-55: +-0.0537 either side) and
+                        # taylor_erf by 4.7e-3 at |x| = 2 (approx.cpp:75-76): a sample point within float noise of
+                        # such a jump may land on either side, so these two variants get the jump x weight as
+                        # tolerance instead of the re-association tolerance
+                        (pkg.EXP_VCL, pkg.ERF_SPLINE_MIRROR, 2e-2),
+                        (pkg.EXP_VCL, pkg.ERF_TAYLOR, 5e-3)]:
         renderer.set_options(ek, rk, 0.0)
         _, rad = renderer.render(origin)
         _, orad = oracle.render(w, h, plane, origin, g, tiles, exp_kind=ek, erf_kind=rk, want_image=False)
