@@ -227,7 +227,9 @@ def main():
                          "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                          "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4); see valu"},
             "valu": {"blocks": st["blocks"], "mean_block_list": st["list_entries"] / max(st["blocks"], 1),
-                     "mean_tile_list": st["tile_entries"] / max(st["blocks"], 1), "overflow_blocks": st["overflow_blocks"]},
+                     "mean_tile_list": st["tile_entries"] / max(st["blocks"], 1), "overflow_blocks": st["overflow_blocks"],
+                     "mean_ray_list": st["lane_entries"] / max(st["rays"], 1),
+                     "mean_block_longest_ray_list": st["lane_max_entries"] / max(st["blocks"], 1)},
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(scene, g, w, h, args.tiles, args.grid, "")

@@ -149,8 +149,10 @@ typedef struct {
     uint64_t rays;           /* rays shaded                                                         */
     uint64_t blocks;         /* 8x8 pixel blocks (one wavefront each)                                */
     uint64_t list_entries;   /* sum over blocks of candidates kept by the block cull                 */
-    uint64_t tile_entries;   /* sum over blocks of their reference-tile list length                  */
-    uint64_t overflow_blocks;/* blocks whose candidate list overflowed LDS (fell back to tile list)  */
+    uint64_t tile_entries;   /* sum over blocks of the (tile-culled) tile list length they scanned    */
+    uint64_t overflow_blocks;/* blocks whose candidates overflowed LDS (streamed the tile list)       */
+    uint64_t lane_entries;   /* sum over rays of the per-ray list length (fast path)                  */
+    uint64_t lane_max_entries;/* sum over blocks of the longest per-ray list (the loop trip count)    */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

@@ -1,8 +1,15 @@
 // vrt_hip_api.cpp -- the C ABI of libvrt_hip.so (see include/vrt_hip.h): context, device-resident
 // scene / tile / ray state, launches.  Compiled with hipcc for gfx950; links only libamdhip64.
 // There is no CPU fallback anywhere in this file: without a GPU vrt_hip_create() fails.
+//
+// Frame pipeline (all on the caller's stream for the *_device entry points):
+//   prep_frame_kernel        only when the origin or the scene changed: oc = mu - origin, |oc|^2
+//   build_tile_lists_kernel  only when tiles / rays / origin / options changed: the reference's tile sets
+//                            (rt.cpp:29-69, or the caller's lists) intersected with a tile-level cull
+//   render_kernel            one wavefront per 8x8 pixel block
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -34,6 +41,8 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+enum TileMode { TILES_NONE = 0, TILES_HOST = 1, TILES_DEVICE = 2 };
+
 } // namespace
 
 struct vrt_hip_ctx {
@@ -52,20 +61,26 @@ struct vrt_hip_ctx {
     bool gA_valid = false;
     float gA_origin[3] = { 0, 0, 0 };
 
-    // tiles
-    bool tiled = false;
+    // tiles.  "ref" lists carry the reference semantics (tiles_t): uploaded by the caller (TILES_HOST), one
+    // tile holding everything (TILES_NONE), or produced on demand for queries (TILES_DEVICE).  "work" lists
+    // are what the render kernel scans: ref lists intersected with the tile-level cull.
+    TileMode tile_mode = TILES_NONE;
     float tw = 2.f, th = 2.f;
     uint32_t tiles_w = 1, tiles_h = 1;
-    DevBuf<uint32_t> t_start, t_count, t_indices;
-    DevBuf<float4> proj;
+    float view[16] = { 0 };
+    DevBuf<uint32_t> ref_start, ref_count, ref_indices;
+    bool ref_valid = false;
+    DevBuf<uint32_t> w_start, w_count, w_indices;
+    bool work_is_ref = false; // render straight from the ref lists (no tile-level cull possible)
+    bool lists_dirty = true;
     DevBuf<float> xc, yc;
-    bool device_binned = false;      // tile lists use the fixed-stride layout of vrt_hip_tile_gaussians
     float grid_tw = 0.f, grid_th = 0.f;
-    uint32_t grid_n = 0;
+    uint32_t grid_n = 0xFFFFFFFFu;
 
     // rays
     uint32_t w = 0, h = 0;
     bool plane_mode = false;
+    bool plane_affine = false; // plane arrays are a pinhole pattern: corner rays bound a tile's cone
     DevBuf<float> xs, ys, zs;
     float cam_pos[3] = { 0, 0, 0 }, cam_right[3] = { 1, 0, 0 }, cam_up[3] = { 0, 1, 0 }, cam_front[3] = { 0, 0, -1 };
     float focal = 1.f;
@@ -111,7 +126,7 @@ float exp_floor_x(int exp_kind)
     switch (exp_kind) {
     case VRT_EXP_VCL: return 87.3f;
     case VRT_EXP_LIBM: return 104.f;
-    case VRT_EXP_FAST: return 88.f; // clamped fast_exp returns 0 for x < -87.3 (a*x+b < 2^23)
+    case VRT_EXP_FAST: return 88.f;   // clamped fast_exp returns 0 for x < -87.3 (a*x+b < 2^23)
     case VRT_EXP_SPLINE: return 9.0f; // spline_exp(x) = 0 for x <= -9 (approx.cpp:143)
     default: return INFINITY;
     }
@@ -130,6 +145,7 @@ int rebuild_tables(vrt_hip_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream)); // later launches may use a caller's stream
     c->tables_dirty = false;
     c->gA_valid = false;
+    c->lists_dirty = true;
     return VRT_HIP_OK;
 }
 
@@ -149,37 +165,24 @@ int prep_frame(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
     HIPCHK(c, hipGetLastError());
     memcpy(c->gA_origin, origin, 3 * sizeof(float));
     c->gA_valid = true;
+    c->lists_dirty = true; // the tile-level cull depends on the origin
     return VRT_HIP_OK;
 }
 
-// tile geometry for the current image size (rt.h:348-349, 364-365)
-TileLists tile_lists(const vrt_hip_ctx *c)
+// tile geometry for the current image size (rt.h:348-349, 364-365); list pointers filled by the caller
+TileLists tile_geometry(const vrt_hip_ctx *c)
 {
-    TileLists t;
-    t.start = c->t_start.p; t.count = c->t_count.p;
-    if (c->tiled) {
-        t.indices = c->t_indices.p;
+    TileLists t{};
+    if (c->tile_mode != TILES_NONE) {
         t.tiles_w = c->tiles_w; t.tiles_h = c->tiles_h;
         t.tile_w = (uint32_t)(uint64_t)(c->w * c->tw / 2.f);
         t.tile_h = (uint32_t)(uint64_t)(c->h * c->th / 2.f);
     } else {
-        t.indices = c->iota.p;
         t.tiles_w = t.tiles_h = 1;
         t.tile_w = c->w; t.tile_h = c->h;
     }
     t.stride = t.tile_w * t.tiles_w;
     return t;
-}
-
-int ensure_untiled_lists(vrt_hip_ctx *c)
-{
-    if (c->tiled) return VRT_HIP_OK;
-    HIPCHK(c, c->t_start.reserve(1)); HIPCHK(c, c->t_count.reserve(1));
-    const uint32_t zero = 0, n = c->n;
-    HIPCHK(c, hipMemcpyAsync(c->t_start.p, &zero, 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->t_count.p, &n, 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VRT_HIP_OK;
 }
 
 RayGen ray_gen(const vrt_hip_ctx *c, const float origin[3])
@@ -197,13 +200,135 @@ RayGen ray_gen(const vrt_hip_ctx *c, const float origin[3])
     return r;
 }
 
+// (Re)builds the tile-centre arrays when the tile grid changes (the reference's float loops, rt.cpp:47-49).
+int prepare_tile_grid(vrt_hip_ctx *c, float tw, float th)
+{
+    std::vector<float> xc, yc;
+    for (float x = -1.f + tw / 2; x < 1.f; x += tw) { xc.push_back(x); if (xc.size() > 4096) break; }
+    for (float y = -1.f + th / 2; y < 1.f; y += th) { yc.push_back(y); if (yc.size() > 4096) break; }
+    const uint32_t tiles_w = (uint32_t)std::ceil(2.f / tw), tiles_h = (uint32_t)std::ceil(2.f / th); // types.h:280
+    if (xc.size() > 4096 || yc.size() > 4096 || tiles_w > 4096 || tiles_h > 4096)
+        return fail(c, VRT_HIP_ERR_INVALID, "tile_gaussians: more than 4096 tiles per axis");
+    // The reference indexes tiles.gaussians[ty*tiles.w + tx] for ty < tiles.h, tx < tiles.w (rt.h:356) while the
+    // float loops produced xc.size() tiles per row; they agree unless 2/t is not representable.  Keep tiles.w x
+    // tiles.h tiles, each tested against the centre the loops would have produced for that row/column.
+    while (xc.size() < tiles_w) xc.push_back(xc.empty() ? -1.f + tw / 2 : xc.back() + tw);
+    while (yc.size() < tiles_h) yc.push_back(yc.empty() ? -1.f + th / 2 : yc.back() + th);
+    const size_t nt = (size_t)tiles_w * tiles_h;
+    if (nt * (size_t)std::max(c->n, 1u) > (size_t)1 << 31)
+        return fail(c, VRT_HIP_ERR_NOMEM, "tile_gaussians: tiles x gaussians too large");
+    HIPCHK(c, c->xc.reserve(tiles_w)); HIPCHK(c, c->yc.reserve(tiles_h));
+    HIPCHK(c, c->w_start.reserve(nt)); HIPCHK(c, c->w_count.reserve(nt)); HIPCHK(c, c->w_indices.reserve(nt * c->n));
+    std::vector<uint32_t> start(nt);
+    for (size_t t = 0; t < nt; ++t) start[t] = (uint32_t)(t * c->n);
+    HIPCHK(c, hipMemcpy(c->xc.p, xc.data(), tiles_w * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->yc.p, yc.data(), tiles_h * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->w_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
+    c->grid_tw = tw; c->grid_th = th; c->grid_n = c->n;
+    if (c->tile_mode != TILES_DEVICE || c->tiles_w != tiles_w || c->tiles_h != tiles_h) c->shard_dirty = true;
+    c->tile_mode = TILES_DEVICE; c->tw = tw; c->th = th; c->tiles_w = tiles_w; c->tiles_h = tiles_h;
+    return VRT_HIP_OK;
+}
+
+BinArgs bin_args(const vrt_hip_ctx *c)
+{
+    BinArgs a{};
+    a.mu_sig = c->mu_sig.p; a.gA = c->gA.p; a.gB = c->gB.p; a.n = c->n;
+    for (int i = 0; i < 16; ++i) a.V.m[i] = c->view[i];
+    a.xc = c->xc.p; a.yc = c->yc.p; a.tw = c->tw; a.th = c->th; a.tiles_w = c->tiles_w;
+    return a;
+}
+
+// The single-tile "everything" list of the untiled overloads (rt.h:227-228, 315-316).
+int ensure_none_ref_lists(vrt_hip_ctx *c)
+{
+    if (c->tile_mode != TILES_NONE || c->ref_valid) return VRT_HIP_OK;
+    HIPCHK(c, c->ref_start.reserve(1)); HIPCHK(c, c->ref_count.reserve(1));
+    const uint32_t zero = 0, n = c->n;
+    HIPCHK(c, hipMemcpy(c->ref_start.p, &zero, 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ref_count.p, &n, 4, hipMemcpyHostToDevice));
+    c->ref_valid = true;
+    return VRT_HIP_OK;
+}
+
+// Reference-semantics lists of the device binning, for queries only (get_tile_counts / get_tile_indices).
+int ensure_device_ref_lists(vrt_hip_ctx *c)
+{
+    if (c->tile_mode != TILES_DEVICE || c->ref_valid) return VRT_HIP_OK;
+    const size_t nt = (size_t)c->tiles_w * c->tiles_h;
+    HIPCHK(c, c->ref_count.reserve(nt)); HIPCHK(c, c->ref_indices.reserve(nt * c->n));
+    BinArgs a = bin_args(c);
+    a.refine = 0;
+    a.out_start = c->w_start.p; a.out_indices = c->ref_indices.p; a.out_count = c->ref_count.p;
+    launch_build_tile_lists(a, false, (uint32_t)nt, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ref_valid = true;
+    return VRT_HIP_OK;
+}
+
+int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
+{
+    if (!c->lists_dirty) return VRT_HIP_OK;
+    int rc = ensure_none_ref_lists(c);
+    if (rc) return rc;
+    const TileLists geo = tile_geometry(c);
+    const size_t nt = (size_t)geo.tiles_w * geo.tiles_h;
+    // the tile cone is built from corner rays: needs pinhole rays (always true for in-kernel ray generation)
+    const bool refine = !c->plane_mode || c->plane_affine;
+    BinArgs a = bin_args(c);
+    a.refine = refine ? 1 : 0;
+    a.R = ray_gen(c, origin);
+    a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
+    c->work_is_ref = false;
+    if (c->tile_mode == TILES_DEVICE) {
+        if (c->grid_n != c->n) { // the scene was replaced after tile_gaussians(): re-stride the list buffers
+            HIPCHK(c, hipStreamSynchronize(st));
+            if ((rc = prepare_tile_grid(c, c->tw, c->th))) return rc;
+            a = bin_args(c);
+            a.refine = refine ? 1 : 0; a.R = ray_gen(c, origin);
+            a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
+        }
+        a.out_start = c->w_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
+        launch_build_tile_lists(a, false, (uint32_t)nt, st);
+    } else if (refine) {
+        const size_t total = c->tile_mode == TILES_NONE ? c->n : c->ref_indices.cap;
+        HIPCHK(c, c->w_count.reserve(nt)); HIPCHK(c, c->w_indices.reserve(total));
+        a.in_start = c->ref_start.p; a.in_count = c->ref_count.p;
+        a.in_indices = c->tile_mode == TILES_NONE ? c->iota.p : c->ref_indices.p;
+        a.tiles_w = geo.tiles_w;
+        a.out_start = c->ref_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
+        launch_build_tile_lists(a, true, (uint32_t)nt, st);
+    } else {
+        c->work_is_ref = true;
+    }
+    HIPCHK(c, hipGetLastError());
+    c->lists_dirty = false;
+    return VRT_HIP_OK;
+}
+
+TileLists work_lists(const vrt_hip_ctx *c)
+{
+    TileLists t = tile_geometry(c);
+    if (c->tile_mode == TILES_DEVICE) {
+        t.start = c->w_start.p; t.count = c->w_count.p; t.indices = c->w_indices.p;
+    } else if (c->work_is_ref) {
+        t.start = c->ref_start.p; t.count = c->ref_count.p;
+        t.indices = c->tile_mode == TILES_NONE ? c->iota.p : c->ref_indices.p;
+    } else {
+        t.start = c->ref_start.p; t.count = c->w_count.p; t.indices = c->w_indices.p;
+    }
+    return t;
+}
+
 // owner of tile t: diagonal interleave, balanced for centred objects
 inline int shard_owner(uint32_t t, uint32_t tiles_w, int world) { return (int)((t + t / tiles_w) % (uint32_t)world); }
 
 int rebuild_shard(vrt_hip_ctx *c)
 {
     if (!c->shard_dirty) return VRT_HIP_OK;
-    const uint32_t tiles_w = c->tiled ? c->tiles_w : 1, ntiles = c->tiled ? c->tiles_w * c->tiles_h : 1;
+    const bool tiled = c->tile_mode != TILES_NONE;
+    const uint32_t tiles_w = tiled ? c->tiles_w : 1, ntiles = tiled ? c->tiles_w * c->tiles_h : 1;
     std::vector<std::vector<uint32_t>> owned(c->world);
     for (uint32_t t = 0; t < ntiles; ++t) owned[shard_owner(t, tiles_w, c->world)].push_back(t);
     size_t slots = 0;
@@ -235,10 +360,11 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     int rc = check_ready(c);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    const TileLists geo = tile_geometry(c);
+    if (geo.tile_w == 0 || geo.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
     if ((rc = prep_frame(c, origin, st))) return rc;
-    if ((rc = ensure_untiled_lists(c))) return rc;
-    TileLists t = tile_lists(c);
-    if (c->tiled && (t.tile_w == 0 || t.tile_h == 0)) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
+    if ((rc = build_work_lists(c, origin, st))) return rc;
+    const TileLists t = work_lists(c);
     RenderTarget o;
     o.image = d_image; o.radiance = d_rad; o.pack_flags = pack_flags;
     o.stats = c->stats_on ? c->d_stats.p : nullptr;
@@ -248,7 +374,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     } else {
         o.tile_map = nullptr; o.n_local_tiles = t.tiles_w * t.tiles_h; o.compact = 0;
     }
-    if (o.stats) HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 3 * sizeof(unsigned long long), st));
+    if (o.stats) HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 8 * sizeof(unsigned long long), st));
     const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
     c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
@@ -257,12 +383,32 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     return VRT_HIP_OK;
 }
 
+// Are the plane arrays an affine function of (row, column)?  Then rays are a pinhole bundle and the
+// corner rays of a tile bound its cone.  Anything else disables the tile-level cull (the per-block cull
+// works from the actual lane rays and stays exact for arbitrary arrays).
+bool plane_is_affine(uint32_t w, uint32_t h, const float *xs, const float *ys, const float *zs)
+{
+    const float *a[3] = { xs, ys, zs };
+    for (int k = 0; k < 3; ++k) {
+        const float *p = a[k];
+        const double p00 = p[0];
+        const double dx = w > 1 ? ((double)p[w - 1] - p00) / (w - 1) : 0.0;
+        const double dy = h > 1 ? ((double)p[(size_t)(h - 1) * w] - p00) / (h - 1) : 0.0;
+        double scale = 1.0;
+        for (uint32_t i = 0; i < h; i += (h > 64 ? h / 64 : 1)) scale = std::max(scale, std::fabs((double)p[(size_t)i * w]));
+        const double tol = 1e-5 * scale;
+        for (uint32_t i = 0; i < h; ++i)
+            for (uint32_t j = 0; j < w; ++j)
+                if (std::fabs((double)p[(size_t)i * w + j] - (p00 + dx * j + dy * i)) > tol) return false;
+    }
+    return true;
+}
+
 } // namespace
 
-// Needed by nothing outside this file; kept out of the anonymous namespace only for clarity.
 extern "C" {
 
-const char *vrt_hip_version(void) { return "vrt_hip 0.1 (gfx950)"; }
+const char *vrt_hip_version(void) { return "vrt_hip 0.2 (gfx950)"; }
 
 int vrt_hip_create(int device, vrt_hip_ctx **out)
 {
@@ -279,7 +425,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        c->d_stats.reserve(4) != hipSuccess) {
+        c->d_stats.reserve(8) != hipSuccess) {
         delete c;
         return fail(nullptr, VRT_HIP_ERR_HIP, "create: stream/event creation failed");
     }
@@ -294,7 +440,8 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->soa) b.release();
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
-    c->t_start.release(); c->t_count.release(); c->t_indices.release(); c->proj.release(); c->xc.release(); c->yc.release();
+    c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
+    c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -323,7 +470,8 @@ int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const flo
     c->has_alpha = aa != nullptr;
     c->n = (uint32_t)n;
     c->tables_dirty = true;
-    if (!c->tiled) c->shard_dirty = true;
+    c->lists_dirty = true;
+    if (c->tile_mode != TILES_HOST) c->ref_valid = false;
     return VRT_HIP_OK;
 }
 
@@ -361,8 +509,8 @@ int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_e
 int vrt_hip_clear_tiles(vrt_hip_ctx *c)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
-    c->tiled = false; c->tw = c->th = 2.f; c->tiles_w = c->tiles_h = 1; c->shard_dirty = true;
-    c->device_binned = false;
+    c->tile_mode = TILES_NONE; c->tw = c->th = 2.f; c->tiles_w = c->tiles_h = 1;
+    c->shard_dirty = true; c->lists_dirty = true; c->ref_valid = false;
     return VRT_HIP_OK;
 }
 
@@ -384,93 +532,73 @@ int vrt_hip_set_tiles(vrt_hip_ctx *c, float tw, float th, uint64_t tiles_w, uint
         if (indices[k] >= c->n) return fail(c, VRT_HIP_ERR_INVALID, "set_tiles: index out of range (upload the scene first)");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, c->t_start.reserve(nt)); HIPCHK(c, c->t_count.reserve(nt)); HIPCHK(c, c->t_indices.reserve(total));
-    HIPCHK(c, hipMemcpy(c->t_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->t_count.p, count.data(), nt * 4, hipMemcpyHostToDevice));
-    if (total) HIPCHK(c, hipMemcpy(c->t_indices.p, indices, total * 4, hipMemcpyHostToDevice));
-    c->tiled = true; c->tw = tw; c->th = th; c->tiles_w = (uint32_t)tiles_w; c->tiles_h = (uint32_t)tiles_h;
-    c->shard_dirty = true;
-    c->device_binned = false;
-    return VRT_HIP_OK;
-}
-
-// (Re)builds the tile-centre arrays and fixed-stride list starts when the tile grid changes.
-static int prepare_tile_grid(vrt_hip_ctx *c, float tw, float th)
-{
-    // tile centres by the reference's float loops (rt.cpp:47-49); tiles_t.w/h = ceil(2/t) (types.h:280)
-    std::vector<float> xc, yc;
-    for (float x = -1.f + tw / 2; x < 1.f; x += tw) { xc.push_back(x); if (xc.size() > 4096) break; }
-    for (float y = -1.f + th / 2; y < 1.f; y += th) { yc.push_back(y); if (yc.size() > 4096) break; }
-    const uint32_t tiles_w = (uint32_t)std::ceil(2.f / tw), tiles_h = (uint32_t)std::ceil(2.f / th);
-    if (xc.size() > 4096 || yc.size() > 4096 || tiles_w > 4096 || tiles_h > 4096)
-        return fail(c, VRT_HIP_ERR_INVALID, "tile_gaussians: more than 4096 tiles per axis");
-    // The reference indexes tiles.gaussians[ty*tiles.w + tx] for ty < tiles.h, tx < tiles.w (rt.h:356) while the
-    // float loops produced xc.size() tiles per row; they agree unless 2/t is not representable.  Keep tiles.w x
-    // tiles.h tiles, each tested against the centre the loops would have produced for that row/column.
-    while (xc.size() < tiles_w) xc.push_back(xc.empty() ? -1.f + tw / 2 : xc.back() + tw);
-    while (yc.size() < tiles_h) yc.push_back(yc.empty() ? -1.f + th / 2 : yc.back() + th);
-    const size_t nt = (size_t)tiles_w * tiles_h;
-    if (nt * (size_t)c->n > (size_t)1 << 31) return fail(c, VRT_HIP_ERR_NOMEM, "tile_gaussians: tiles x gaussians too large");
-    HIPCHK(c, c->xc.reserve(tiles_w)); HIPCHK(c, c->yc.reserve(tiles_h)); HIPCHK(c, c->proj.reserve(c->n));
-    HIPCHK(c, c->t_start.reserve(nt)); HIPCHK(c, c->t_count.reserve(nt)); HIPCHK(c, c->t_indices.reserve(nt * c->n));
-    std::vector<uint32_t> start(nt);
-    for (size_t t = 0; t < nt; ++t) start[t] = (uint32_t)(t * c->n);
-    HIPCHK(c, hipMemcpy(c->xc.p, xc.data(), tiles_w * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->yc.p, yc.data(), tiles_h * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->t_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
-    c->grid_tw = tw; c->grid_th = th; c->grid_n = c->n;
-    if (!c->tiled || c->tiles_w != tiles_w || c->tiles_h != tiles_h) c->shard_dirty = true;
-    c->tiled = true; c->tw = tw; c->th = th; c->tiles_w = tiles_w; c->tiles_h = tiles_h;
-    c->device_binned = true;
+    // exact-size index buffer: build_work_lists sizes its output from ref_indices.cap
+    c->ref_indices.release();
+    HIPCHK(c, c->ref_start.reserve(nt)); HIPCHK(c, c->ref_count.reserve(nt)); HIPCHK(c, c->ref_indices.reserve(total));
+    HIPCHK(c, hipMemcpy(c->ref_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ref_count.p, count.data(), nt * 4, hipMemcpyHostToDevice));
+    if (total) HIPCHK(c, hipMemcpy(c->ref_indices.p, indices, total * 4, hipMemcpyHostToDevice));
+    c->tile_mode = TILES_HOST; c->tw = tw; c->th = th; c->tiles_w = (uint32_t)tiles_w; c->tiles_h = (uint32_t)tiles_h;
+    c->shard_dirty = true; c->lists_dirty = true; c->ref_valid = true;
     return VRT_HIP_OK;
 }
 
 int vrt_hip_tile_gaussians_device(vrt_hip_ctx *c, float tw, float th, const float view[16], void *hip_stream)
 {
+    (void)hip_stream; // the lists are built by the next render on ITS stream (they depend on its rays and origin)
     if (!c) return VRT_HIP_ERR_INVALID;
     if (!view || !(tw > 0.f) || !(th > 0.f)) return fail(c, VRT_HIP_ERR_INVALID, "tile_gaussians: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = rebuild_tables(c);
     if (rc) return rc;
-    if (!c->device_binned || c->grid_tw != tw || c->grid_th != th || c->grid_n != c->n) {
+    if (c->tile_mode != TILES_DEVICE || c->grid_tw != tw || c->grid_th != th || c->grid_n != c->n) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if ((rc = prepare_tile_grid(c, tw, th))) return rc;
     }
-    hipStream_t st = (hipStream_t)hip_stream;
-    launch_project(tables(c), view, c->proj.p, st);
-    launch_bin_tiles(c->proj.p, c->n, c->xc.p, c->yc.p, c->tiles_w, c->tiles_h, tw, th, c->t_indices.p, c->t_count.p, st);
-    HIPCHK(c, hipGetLastError());
+    memcpy(c->view, view, 16 * sizeof(float));
+    c->lists_dirty = true;
+    c->ref_valid = false;
     return VRT_HIP_OK;
 }
 
 int vrt_hip_tile_gaussians(vrt_hip_ctx *c, float tw, float th, const float view[16])
 {
     if (!c) return VRT_HIP_ERR_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
+    int rc = vrt_hip_tile_gaussians_device(c, tw, th, view, nullptr);
+    if (rc) return rc;
+    // the synchronous form also materialises the reference-semantics lists (what tiles_t would hold), timed
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    int rc = vrt_hip_tile_gaussians_device(c, tw, th, view, c->stream);
-    if (rc) return rc;
+    const size_t nt = (size_t)c->tiles_w * c->tiles_h;
+    HIPCHK(c, c->ref_count.reserve(nt)); HIPCHK(c, c->ref_indices.reserve(nt * c->n));
+    BinArgs a = bin_args(c);
+    a.refine = 0;
+    a.out_start = c->w_start.p; a.out_indices = c->ref_indices.p; a.out_count = c->ref_count.p;
+    launch_build_tile_lists(a, false, (uint32_t)nt, c->stream);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.tiling_ms = ms;
+    c->ref_valid = true;
     return VRT_HIP_OK;
 }
 
 int vrt_hip_get_tile_counts(vrt_hip_ctx *c, uint32_t *counts, size_t cap, uint64_t *tiles_w, uint64_t *tiles_h)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
-    if (!c->tiled) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_counts: no tiles set");
+    if (c->tile_mode == TILES_NONE) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_counts: no tiles set");
     const size_t nt = (size_t)c->tiles_w * c->tiles_h;
     if (tiles_w) *tiles_w = c->tiles_w;
     if (tiles_h) *tiles_h = c->tiles_h;
     if (counts) {
         if (cap < nt) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_counts: buffer too small");
         HIPCHK(c, hipSetDevice(c->device));
+        int rc = ensure_device_ref_lists(c);
+        if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy(counts, c->t_count.p, nt * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(counts, c->ref_count.p, nt * 4, hipMemcpyDeviceToHost));
     }
     return VRT_HIP_OK;
 }
@@ -478,16 +606,20 @@ int vrt_hip_get_tile_counts(vrt_hip_ctx *c, uint32_t *counts, size_t cap, uint64
 int vrt_hip_get_tile_indices(vrt_hip_ctx *c, uint64_t t, uint32_t *indices, size_t cap, uint32_t *count)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
-    if (!c->tiled || t >= (uint64_t)c->tiles_w * c->tiles_h) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_indices: bad tile");
+    if (c->tile_mode == TILES_NONE || t >= (uint64_t)c->tiles_w * c->tiles_h)
+        return fail(c, VRT_HIP_ERR_INVALID, "get_tile_indices: bad tile");
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_device_ref_lists(c);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t *starts = c->tile_mode == TILES_DEVICE ? c->w_start.p : c->ref_start.p;
     uint32_t start = 0, cnt = 0;
-    HIPCHK(c, hipMemcpy(&start, c->t_start.p + t, 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&cnt, c->t_count.p + t, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&start, starts + t, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&cnt, c->ref_count.p + t, 4, hipMemcpyDeviceToHost));
     if (count) *count = cnt;
     if (indices) {
         if (cap < cnt) return fail(c, VRT_HIP_ERR_INVALID, "get_tile_indices: buffer too small");
-        if (cnt) HIPCHK(c, hipMemcpy(indices, c->t_indices.p + start, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (cnt) HIPCHK(c, hipMemcpy(indices, c->ref_indices.p + start, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     }
     return VRT_HIP_OK;
 }
@@ -503,7 +635,8 @@ int vrt_hip_set_plane(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float *xs, c
     HIPCHK(c, hipMemcpy(c->xs.p, xs, n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->ys.p, ys, n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->zs.p, zs, n * 4, hipMemcpyHostToDevice));
-    c->w = w; c->h = h; c->plane_mode = true; c->rays_set = true;
+    c->plane_affine = plane_is_affine(w, h, xs, ys, zs);
+    c->w = w; c->h = h; c->plane_mode = true; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
 
@@ -513,7 +646,7 @@ int vrt_hip_set_camera(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float pos[3
     if (!c) return VRT_HIP_ERR_INVALID;
     if (!w || !h || !pos || !right || !up || !front) return fail(c, VRT_HIP_ERR_INVALID, "set_camera: bad argument");
     memcpy(c->cam_pos, pos, 12); memcpy(c->cam_right, right, 12); memcpy(c->cam_up, up, 12); memcpy(c->cam_front, front, 12);
-    c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->rays_set = true;
+    c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
 
@@ -535,8 +668,9 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     if (radiance_out) HIPCHK(c, c->d_rad.reserve(npix));
     HIPCHK(c, hipMemsetAsync(c->d_image.p, 0, npix * 4, c->stream));
     if (radiance_out) HIPCHK(c, hipMemsetAsync(c->d_rad.p, 0, npix * 16, c->stream));
-    // tables / frame prep outside the timed kernel window
+    // tables / frame prep / tile lists outside the timed kernel window
     if ((rc = prep_frame(c, origin, c->stream))) return rc;
+    if ((rc = build_work_lists(c, origin, c->stream))) return rc;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     rc = render_common(c, origin, pack_flags, c->d_image.p, radiance_out ? c->d_rad.p : nullptr, c->stream, false);
     if (rc) return rc;
@@ -546,9 +680,10 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
     if (c->stats_on) {
-        unsigned long long st[3];
+        unsigned long long st[5];
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
         c->last.list_entries = st[0]; c->last.tile_entries = st[1]; c->last.overflow_blocks = st[2];
+        c->last.lane_entries = st[3]; c->last.lane_max_entries = st[4];
     }
     if (image_out) HIPCHK(c, hipMemcpy(image_out, c->d_image.p, npix * 4, hipMemcpyDeviceToHost));
     if (radiance_out) HIPCHK(c, hipMemcpy(radiance_out, c->d_rad.p, npix * 16, hipMemcpyDeviceToHost));
@@ -568,7 +703,7 @@ size_t vrt_hip_shard_pixels(const vrt_hip_ctx *cc)
     vrt_hip_ctx *c = const_cast<vrt_hip_ctx *>(cc);
     if (!c || !c->rays_set) return 0;
     if (rebuild_shard(c)) return 0;
-    const TileLists t = tile_lists(c);
+    const TileLists t = tile_geometry(c);
     return (size_t)c->n_slots * t.tile_w * t.tile_h;
 }
 
@@ -585,7 +720,7 @@ int vrt_hip_assemble_shards_device(vrt_hip_ctx *c, const uint32_t *d_gathered, u
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = rebuild_shard(c))) return rc;
-    launch_assemble(d_gathered, d_image, c->slot_tiles.p, c->n_slots * (uint32_t)c->world, tile_lists(c), c->w, c->h,
+    launch_assemble(d_gathered, d_image, c->slot_tiles.p, c->n_slots * (uint32_t)c->world, tile_geometry(c), c->w, c->h,
                     (hipStream_t)hip_stream);
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;

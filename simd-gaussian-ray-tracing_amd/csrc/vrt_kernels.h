@@ -8,7 +8,8 @@ namespace vrtk {
 
 constexpr int BLOCK_W = 8;        // one wavefront = one 8x8 pixel block (64 rays)
 constexpr int BLOCK_H = 8;
-constexpr int LIST_CAP = 1024;    // per-block candidate list in LDS (u32 indices)
+constexpr int PCAP = 192;         // per-block candidates cached in LDS (index + two parameter rows = 36 B each)
+constexpr int PL = 48;            // per-lane list capacity (u8 positions into the block's candidates)
 
 // Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
 struct SceneTables {
@@ -46,7 +47,8 @@ struct RenderTarget {
     const uint32_t *tile_map;
     uint32_t n_local_tiles;
     int compact;
-    unsigned long long *stats; // nullable: [0]=list entries [1]=tile entries [2]=overflow blocks
+    unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
+                               // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list
 };
 
 void launch_prep_frame(const SceneTables &s, float4 *gA_out, const float origin[3], hipStream_t st);
@@ -57,10 +59,27 @@ void launch_build_static(uint32_t n, const float *mu_x, const float *mu_y, const
 void launch_render(const SceneTables &s, const TileLists &t, const RayGen &r, const RenderTarget &o, int exp_kind,
                    int erf_kind, hipStream_t st);
 
-// tile binning (rt.cpp:29-69)
-void launch_project(const SceneTables &s, const float view[16], float4 *proj_out, hipStream_t st);
-void launch_bin_tiles(const float4 *proj, uint32_t n, const float *xc, const float *yc, uint32_t tiles_w,
-                      uint32_t tiles_h, float tw, float th, uint32_t *indices, uint32_t *counts, hipStream_t st);
+// per-tile list construction: tile binning (rt.cpp:29-69) and/or tile-level cull ("refine")
+struct Mat4 { float m[16]; };
+struct BinArgs {
+    const float4 *mu_sig, *gA, *gB;
+    uint32_t n;
+    // input: caller-made lists (from_list) ...
+    const uint32_t *in_start, *in_count, *in_indices;
+    // ... or on-device binning with the reference's test
+    Mat4 V;
+    const float *xc, *yc;
+    float tw, th;
+    uint32_t tiles_w;
+    // tile-level cull
+    int refine;
+    RayGen R;
+    uint32_t tile_w, tile_h, stride;
+    // output: list of tile t at out_indices[out_start[t] ...], length out_count[t]
+    const uint32_t *out_start;
+    uint32_t *out_indices, *out_count;
+};
+void launch_build_tile_lists(const BinArgs &a, bool from_list, uint32_t ntiles, hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t n_slots,
                      const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
 void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);

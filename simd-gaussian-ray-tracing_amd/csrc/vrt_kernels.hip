@@ -189,28 +189,98 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Image kernel: one wavefront per 8x8 pixel block of one reference tile.
+// Fast path of the image kernel: the block's candidates sit in LDS (index + the two parameter rows the
+// inner loop needs) and every lane walks ITS OWN list of them -- the candidates whose sigma*mag*exp(-x)
+// reaches cull_eps on that lane's ray.  In sparse scenes (sigma of a pixel or two) a ray meets a third of
+// its block's candidates, and the pair loop is quadratic in the list length.  All lanes run the loops to
+// the longest lane list; a lane past the end of its list adds exact zeros (A = 0).
 // ---------------------------------------------------------------------------------------------
 template <int EXP, int ERF, int EC>
-__global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, RayGen R, RenderTarget O,
-                                                     uint32_t blocks_x, uint32_t blocks_y)
+__device__ __forceinline__ void shade_lanes(const SceneTables &S, const uint32_t *s_idx, const float4 *s_A,
+                                            const float4 *s_B, const uint8_t *s_lane /*[k*64 + lane]*/, uint32_t nl,
+                                            uint32_t nmax, uint32_t lane, const LaneRay &ray, float &Lr, float &Lg,
+                                            float &Lb, float &La)
 {
-    __shared__ uint32_t s_list[LIST_CAP];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t bpt = blocks_x * blocks_y;
-    const uint32_t lt = blockIdx.x / bpt, b = blockIdx.x % bpt;
-    const uint32_t t = O.tile_map ? O.tile_map[lt] : lt;
-    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
-    const uint32_t bxi = b % blocks_x, byi = b / blocks_x;
+    Lr = Lg = Lb = La = 0.f;
+    for (uint32_t i0 = 0; i0 < nmax; i0 += EC) {
+        float e_mubar[EC], e_sigma[EC];
+        uint32_t e_li[EC];
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            const bool ve = i0 + e < nl;
+            e_li[e] = ve ? s_lane[(i0 + e) * 64 + lane] : 0u;
+            const float4 a = s_A[e_li[e]];
+            e_mubar[e] = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+            e_sigma[e] = S.gD[s_idx[e_li[e]]].x;
+        }
+        float acc[EC][5];
+#pragma unroll
+        for (int e = 0; e < EC; ++e)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[e][k] = 0.f;
 
-    // ---- this lane's pixel and ray (rt.h:362-371) ----
-    const uint32_t pxt = bxi * BLOCK_W + (lane & 7), pyt = byi * BLOCK_H + (lane >> 3);
-    bool valid = pxt < T.tile_w && pyt < T.tile_h;
-    const uint32_t pxc = min(pxt, T.tile_w - 1), pyc = min(pyt, T.tile_h - 1);
-    const uint64_t npix = (uint64_t)R.width * R.height;
-    uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
-    if (pix >= npix) { valid = false; pix = npix - 1; }
+        // absorber stream over this lane's list; next entry's LDS rows are fetched one iteration ahead
+        uint32_t lj = nl ? s_lane[lane] : 0u;
+        float4 a = s_A[lj], b = s_B[lj];
+        for (uint32_t j = 0; j < nmax; ++j) {
+            const float4 ca = a, cb = b;
+            const bool vj = j < nl;
+            if (j + 1 < nmax) {
+                lj = (j + 1 < nl) ? s_lane[(j + 1) * 64 + lane] : 0u;
+                a = s_A[lj]; b = s_B[lj];
+            }
+            const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+            const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+            const float A = vj ? cb.z * vexp<EXP>(-(d2 * cb.y)) : 0.f;
+            const float m = mubar * cb.x;
+            const float E = verf<ERF>(-m);
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+                const float base = __builtin_fmaf(e_mubar[e], cb.x, -m);
+                const float step = e_sigma[e] * cb.x;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float x = __builtin_fmaf((float)(k - 4), step, base);
+                    acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
+                }
+            }
+        }
 
+        // emission (see shade_list)
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            if (i0 + e < nl) {
+                const uint32_t idx = s_idx[e_li[e]];
+                const float4 ms = S.mu_sig[idx];
+                const float inv2s2 = s_B[e_li[e]].y;
+                const float q = S.gD[idx].y;
+                float inner = 0.f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[e]);
+                    const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
+                    const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
+                    const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
+                    const float dd = dot3_ref(px, py, pz, px, py, pz);
+                    const float T = vexp<EXP>(acc[e][k]);
+                    inner = __builtin_fmaf(q * vexp<EXP>(-(dd * inv2s2)), T, inner);
+                }
+                const float4 alb = S.gC[idx];
+                Lr = __builtin_fmaf(alb.x, inner, Lr);
+                Lg = __builtin_fmaf(alb.y, inner, Lg);
+                Lb = __builtin_fmaf(alb.z, inner, Lb);
+                La = __builtin_fmaf(alb.w, inner, La);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rays and cones
+// ---------------------------------------------------------------------------------------------
+// World-space ray through raster pixel `pix` (rt.h:362-371).
+__device__ __forceinline__ LaneRay pixel_ray(const RayGen &R, uint64_t pix)
+{
     float px, py, pz;
     if (R.xs) {
         px = R.xs[pix]; py = R.ys[pix]; pz = R.zs[pix];
@@ -225,67 +295,138 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     }
     LaneRay ray;
     ray.ox = R.origin[0]; ray.oy = R.origin[1]; ray.oz = R.origin[2];
-    {
-        // rt.h:366-371 + vec4f_t::normalize (types.h:75-82): IEEE sqrt and divides, unfused dot
-        const float dx = px - ray.ox, dy = py - ray.oy, dz = pz - ray.oz;
-        // (sqrtf and '/' are correctly rounded in HIP's default mode; __fsqrt_rn is NOT -- it maps to the
-        // 1-ulp v_sqrt_f32, and a 1-ulp change of n is amplified by the cancellation noise above)
-        const float norm = __builtin_sqrtf(dot3_ref(dx, dy, dz, dx, dy, dz));
-        ray.nx = dx / norm; ray.ny = dy / norm; ray.nz = dz / norm;
-    }
+    // rt.h:366-371 + vec4f_t::normalize (types.h:75-82): IEEE sqrt and divides, unfused dot.
+    // (sqrtf and '/' are correctly rounded in HIP's default mode; __fsqrt_rn is NOT -- it maps to the
+    // 1-ulp v_sqrt_f32, and a 1-ulp change of n is amplified by the cancellation noise above)
+    const float dx = px - ray.ox, dy = py - ray.oy, dz = pz - ray.oz;
+    const float norm = __builtin_sqrtf(dot3_ref(dx, dy, dz, dx, dy, dz));
+    ray.nx = dx / norm; ray.ny = dy / norm; ray.nz = dz / norm;
+    return ray;
+}
 
-    // ---- block cone: axis c and the largest angle of any lane's ray to it ----
-    float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
-    float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
-    float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
-    {
-        const float inv = 1.f / sqrtf(cx * cx + cy * cy + cz * cz);
-        cx *= inv; cy *= inv; cz *= inv;
-    }
-    float cos_t = fminf(wave_min(ray.nx * cx + ray.ny * cy + ray.nz * cz), 1.f);
-    float sin_t = sqrtf(fmaxf(0.f, 1.f - cos_t * cos_t));
-    cos_t = cos_t * 0.9999f;            // conservative: never over-estimate the distance to the cone
-    sin_t = sin_t * 1.0001f + 1e-6f;
+// A bundle of rays from one origin inside the cone (axis c, half angle theta).  For a Gaussian at
+// oc = mu - o the distance to any line of the bundle is >= |oc| sin(phi - theta), phi = angle(oc, axis line)
+// = dperp cos(theta) - |oc.c| sin(theta); the Gaussian can be dropped for the whole bundle when even that
+// best case gives d^2/(2 sigma^2) > cull_x, i.e. sigma*mag*exp(-..) < cull_eps (or Exp underflows to 0).
+struct Cone { float cx, cy, cz, cos_t, sin_t; };
+__device__ __forceinline__ Cone make_cone(float cx, float cy, float cz, float min_dot)
+{
+    Cone k;
+    k.cx = cx; k.cy = cy; k.cz = cz;
+    const float c = fminf(min_dot, 1.f);
+    k.sin_t = sqrtf(fmaxf(0.f, 1.f - c * c)) * 1.0001f + 1e-6f; // conservative: never over-estimate
+    k.cos_t = c * 0.9999f;                                       // the distance to the cone
+    return k;
+}
+__device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/, float4 bq /*r,1/2s^2,qK,cull_x*/)
+{
+    const float tc = a.x * k.cx + a.y * k.cy + a.z * k.cz;
+    const float dperp = sqrtf(fmaxf(0.f, a.w - tc * tc));
+    const float dmin = fmaxf(0.f, dperp * k.cos_t - fabsf(tc) * k.sin_t);
+    const float xmin = dmin * dmin * bq.y;
+    return !(xmin * 0.999f - 1e-3f > bq.w);
+}
 
-    // ---- block cull over the reference tile's list (ballot compaction, order preserving) ----
+// ---------------------------------------------------------------------------------------------
+// Image kernel: one wavefront per 8x8 pixel block of one reference tile.
+// ---------------------------------------------------------------------------------------------
+template <int EXP, int ERF, int EC>
+__global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, RayGen R, RenderTarget O,
+                                                     uint32_t blocks_x, uint32_t blocks_y)
+{
+    __shared__ uint32_t s_idx[PCAP];
+    __shared__ float4 s_A[PCAP], s_B[PCAP];
+    __shared__ uint8_t s_lane[PL * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t bpt = blocks_x * blocks_y;
+    const uint32_t lt = blockIdx.x / bpt, b = blockIdx.x % bpt;
+    const uint32_t t = O.tile_map ? O.tile_map[lt] : lt;
+    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+    const uint32_t bxi = b % blocks_x, byi = b / blocks_x;
+
+    // ---- this lane's pixel ----
+    const uint32_t pxt = bxi * BLOCK_W + (lane & 7), pyt = byi * BLOCK_H + (lane >> 3);
+    bool valid = pxt < T.tile_w && pyt < T.tile_h;
+    const uint32_t pxc = min(pxt, T.tile_w - 1), pyc = min(pyt, T.tile_h - 1);
+    const uint64_t npix = (uint64_t)R.width * R.height;
+    uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
+    if (pix >= npix) { valid = false; pix = npix - 1; }
+    const uint64_t out = O.compact ? ((uint64_t)lt * T.tile_h + pyt) * T.tile_w + pxt : pix;
+
     const uint32_t n_tile = T.count[t];
-    const uint32_t *tile_list = T.indices + T.start[t];
-    uint32_t cnt = 0;
-    for (uint32_t base = 0; base < n_tile; base += 64) {
-        const uint32_t k = base + lane;
-        bool keep = false;
-        uint32_t idx = 0;
-        if (k < n_tile) {
-            idx = tile_list[k];
-            const float4 a = S.gA[idx];
-            const float4 bq = S.gB[idx];
-            const float tc = a.x * cx + a.y * cy + a.z * cz;
-            const float dperp = sqrtf(fmaxf(0.f, a.w - tc * tc));
-            const float dmin = fmaxf(0.f, dperp * cos_t - fabsf(tc) * sin_t);
-            const float xmin = dmin * dmin * bq.y;
-            keep = !(xmin * 0.999f - 1e-3f > bq.w);
-        }
-        const unsigned long long mask = __ballot(keep);
-        const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-        if (keep && pos < LIST_CAP) s_list[pos] = idx;
-        cnt += (uint32_t)__popcll(mask);
-    }
-    __syncthreads();
-    const bool overflow = cnt > LIST_CAP;
-    const uint32_t *list = overflow ? tile_list : (const uint32_t *)s_list;
-    const uint32_t n = overflow ? n_tile : cnt;
-    if (O.stats && lane == 0) {
-        atomicAdd(&O.stats[0], (unsigned long long)n);
-        atomicAdd(&O.stats[1], (unsigned long long)n_tile);
-        if (overflow) atomicAdd(&O.stats[2], 1ull);
-    }
+    float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
+    if (n_tile != 0) { // wave-uniform: empty tiles only clear their pixels
+        const LaneRay ray = pixel_ray(R, pix);
 
-    float Lr, Lg, Lb, La;
-    shade_list<EXP, ERF, EC, true>(S, list, n, ray, Lr, Lg, Lb, La);
+        // ---- block cone: axis = mean of the four centre rays, angle = farthest lane ----
+        float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
+        float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
+        float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
+        {
+            const float inv = 1.f / sqrtf(cx * cx + cy * cy + cz * cz);
+            cx *= inv; cy *= inv; cz *= inv;
+        }
+        const Cone cone = make_cone(cx, cy, cz, wave_min(ray.nx * cx + ray.ny * cy + ray.nz * cz));
+
+        // ---- block cull over the tile's list (ballot compaction, order preserving) ----
+        const uint32_t *tile_list = T.indices + T.start[t];
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < n_tile; base += 64) {
+            const uint32_t k = base + lane;
+            bool keep = false;
+            uint32_t idx = 0;
+            float4 a, bq;
+            if (k < n_tile) {
+                idx = tile_list[k];
+                a = S.gA[idx]; bq = S.gB[idx];
+                keep = cone_keeps(cone, a, bq);
+            }
+            const unsigned long long mask = __ballot(keep);
+            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            if (keep && pos < PCAP) { s_idx[pos] = idx; s_A[pos] = a; s_B[pos] = bq; }
+            cnt += (uint32_t)__popcll(mask);
+        }
+        __syncthreads();
+
+        // ---- lane cull: this ray's own candidates (exact per-ray criterion x > cull_x, no margin needed) ----
+        uint32_t nl = 0;
+        bool fast = cnt <= PCAP;
+        if (fast) {
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float4 a = s_A[j], bq = s_B[j];
+                const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+                const float x = sub_ref(a.w, mul_ref(mubar, mubar)) * bq.y;
+                if (!(x > bq.w)) {
+                    if (nl < PL) s_lane[nl * 64 + lane] = (uint8_t)j;
+                    ++nl;
+                }
+            }
+            fast = __ballot(nl > PL) == 0ull;
+        }
+        __syncthreads();
+        if (O.stats && lane == 0) {
+            atomicAdd(&O.stats[0], (unsigned long long)(cnt <= PCAP ? cnt : n_tile));
+            atomicAdd(&O.stats[1], (unsigned long long)n_tile);
+            if (!fast) atomicAdd(&O.stats[2], 1ull);
+        }
+        if (fast) {
+            uint32_t nmax = nl;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+            if (O.stats) {
+                unsigned long long tot = nl;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((int)tot, off, 64);
+                if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); }
+            }
+            shade_lanes<EXP, ERF, EC>(S, s_idx, s_A, s_B, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+        } else {
+            // candidates do not fit LDS: stream the tile's list through scalar loads (any length)
+            shade_list<EXP, ERF, 4, true>(S, tile_list, n_tile, ray, Lr, Lg, Lb, La);
+        }
+    }
 
     if (valid) {
-        uint64_t out = pix;
-        if (O.compact) out = ((uint64_t)lt * T.tile_h + pyt) * T.tile_w + pxt;
         if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
         if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
     }
@@ -380,73 +521,106 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tile binning: vrt/rt.cpp:29-69 on device.  Arithmetic is kept unfused and in the reference's
-// order so that inclusion decisions (a "<=" on floats) reproduce the host algorithm.
+// Per-tile Gaussian lists.  One 1024-thread workgroup per reference tile builds, in one pass,
+//   (a) the reference's tile set: vrt/rt.cpp:29-69 on device (or takes a caller-made list), and
+//   (b) optionally ("refine") drops from it every Gaussian that is below cull_eps for the whole tile
+//       (cone through the tile's corner rays), so that the 8x8-block cull of the render kernel
+//       scans tens of candidates instead of the reference's ~1600.
+// The reference-set arithmetic is kept unfused and in the reference's order so that inclusion
+// decisions (a "<=" on floats) reproduce the host algorithm; order of indices is preserved.
 // ---------------------------------------------------------------------------------------------
-struct Mat4 { float m[16]; };
-
-__global__ void project_kernel(uint32_t n, const float4 *mu_sig, Mat4 V, float4 *proj)
+template <bool FROM_LIST>
+__global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P)
 {
-#pragma clang fp contract(off)
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 g = mu_sig[i];
-    // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
-    const float x = (V.m[0] * g.x + V.m[4] * g.y) + (V.m[8] * g.z + V.m[12] * 1.f);
-    const float y = (V.m[1] * g.x + V.m[5] * g.y) + (V.m[9] * g.z + V.m[13] * 1.f);
-    const float z = (V.m[2] * g.x + V.m[6] * g.y) + (V.m[10] * g.z + V.m[14] * 1.f);
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!(z < 1.f)) {                       // rt.cpp:38
-        const float sig = g.w / z;          // rt.cpp:40
-        if (!(sig < 1e-5f)) out = make_float4(x / z, y / z, sig, 1.f); // rt.cpp:39-41
+    __shared__ uint32_t s_wave_cnt[16];
+    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tx = t % P.tiles_w, ty = t / P.tiles_w;
+
+    // (b) tile cone from the centre and the four corner pixels of the tile (pinhole rays: the
+    // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
+    Cone cone = {};
+    if (P.refine) {
+        const uint64_t npix = (uint64_t)P.R.width * P.R.height;
+        const uint32_t x0 = tx * P.tile_w, y0 = ty * P.tile_h, x1 = x0 + P.tile_w - 1, y1 = y0 + P.tile_h - 1;
+        auto at = [&](uint32_t x, uint32_t y) {
+            uint64_t pix = (uint64_t)x + (uint64_t)P.stride * y;
+            if (pix >= npix) pix = npix - 1;
+            return pixel_ray(P.R, pix);
+        };
+        const LaneRay c = at(x0 + P.tile_w / 2, y0 + P.tile_h / 2);
+        float md = 1.f;
+        const LaneRay k0 = at(x0, y0), k1 = at(x1, y0), k2 = at(x0, y1), k3 = at(x1, y1);
+        md = fminf(md, k0.nx * c.nx + k0.ny * c.ny + k0.nz * c.nz);
+        md = fminf(md, k1.nx * c.nx + k1.ny * c.ny + k1.nz * c.nz);
+        md = fminf(md, k2.nx * c.nx + k2.ny * c.ny + k2.nz * c.nz);
+        md = fminf(md, k3.nx * c.nx + k3.ny * c.ny + k3.nz * c.nz);
+        cone = make_cone(c.nx, c.ny, c.nz, md);
+        cone.sin_t += 1e-4f; // the centre pixel is up to half a pixel off the rectangle's centre
     }
-    proj[i] = out;
-}
 
-void launch_project(const SceneTables &s, const float view[16], float4 *proj_out, hipStream_t st)
-{
-    if (!s.n) return;
-    Mat4 V;
-    for (int i = 0; i < 16; ++i) V.m[i] = view[i];
-    hipLaunchKernelGGL(project_kernel, dim3((s.n + 255) / 256), dim3(256), 0, st, s.n, s.mu_sig, V, proj_out);
-}
-
-// one wavefront per tile; list of tile t lives at indices[t*n .. t*n + counts[t])
-__global__ __launch_bounds__(64) void bin_tiles_kernel(const float4 *proj, uint32_t n, const float *xc, const float *yc,
-                                                        uint32_t tiles_w, float tw, float th, uint32_t *indices,
-                                                        uint32_t *counts)
-{
+    float x = 0.f, y = 0.f, ax = 0.f, ay = 0.f;
+    uint32_t n_in;
+    const uint32_t *in_list = nullptr;
+    if constexpr (FROM_LIST) {
+        n_in = P.in_count[t];
+        in_list = P.in_indices + P.in_start[t];
+    } else {
 #pragma clang fp contract(off)
-    const uint32_t t = blockIdx.x, lane = threadIdx.x;
-    const float x = xc[t % tiles_w], y = yc[t / tiles_w];
-    const float ax = fabsf(x) + tw / 2, ay = fabsf(y) + th / 2; // rt.cpp:58-59 (left-to-right sums)
-    uint32_t *out = indices + (size_t)t * n;
-    uint32_t cnt = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + lane;
+        n_in = P.n;
+        x = P.xc[tx]; y = P.yc[ty];
+        ax = fabsf(x) + P.tw / 2; ay = fabsf(y) + P.th / 2; // rt.cpp:58-59 (left-to-right sums)
+    }
+    uint32_t *out = P.out_indices + P.out_start[t];
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < n_in; base += 1024) {
+        const uint32_t k = base + tid;
         bool keep = false;
-        if (i < n) {
-            const float4 p = proj[i];
-            if (p.w != 0.f) {
-                const float dx = fabsf(x - p.x), dy = fabsf(y - p.y);
-                const float s33 = 3.3f * p.z;
-                keep = (dx <= ax + s33) && (dy <= ay + s33);
+        uint32_t idx = 0;
+        if (k < n_in) {
+            if constexpr (FROM_LIST) {
+                idx = in_list[k];
+                keep = true;
+            } else {
+#pragma clang fp contract(off)
+                idx = k;
+                const float4 g = P.mu_sig[idx];
+                // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
+                const float vx = (P.V.m[0] * g.x + P.V.m[4] * g.y) + (P.V.m[8] * g.z + P.V.m[12] * 1.f);
+                const float vy = (P.V.m[1] * g.x + P.V.m[5] * g.y) + (P.V.m[9] * g.z + P.V.m[13] * 1.f);
+                const float vz = (P.V.m[2] * g.x + P.V.m[6] * g.y) + (P.V.m[10] * g.z + P.V.m[14] * 1.f);
+                if (!(vz < 1.f)) {                       // rt.cpp:38
+                    const float sig = g.w / vz;          // rt.cpp:40
+                    if (!(sig < 1e-5f)) {                // rt.cpp:41
+                        const float dx = fabsf(x - vx / vz), dy = fabsf(y - vy / vz);
+                        const float s33 = 3.3f * sig;
+                        keep = (dx <= ax + s33) && (dy <= ay + s33); // rt.cpp:58-59
+                    }
+                }
             }
+            if (keep && P.refine) keep = cone_keeps(cone, P.gA[idx], P.gB[idx]);
         }
         const unsigned long long mask = __ballot(keep);
-        const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-        if (keep) out[pos] = i;
-        cnt += (uint32_t)__popcll(mask);
+        if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0, chunk = 0;
+#pragma unroll
+        for (uint32_t wv = 0; wv < 16; ++wv) {
+            const uint32_t c = s_wave_cnt[wv];
+            before += (wv < wave) ? c : 0;
+            chunk += c;
+        }
+        if (keep) out[total + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0))] = idx;
+        total += chunk;
+        __syncthreads();
     }
-    if (lane == 0) counts[t] = cnt;
+    if (tid == 0) P.out_count[t] = total;
 }
 
-void launch_bin_tiles(const float4 *proj, uint32_t n, const float *xc, const float *yc, uint32_t tiles_w,
-                      uint32_t tiles_h, float tw, float th, uint32_t *indices, uint32_t *counts, hipStream_t st)
+void launch_build_tile_lists(const BinArgs &a, bool from_list, uint32_t ntiles, hipStream_t st)
 {
-    if (tiles_w * tiles_h == 0) return;
-    hipLaunchKernelGGL(bin_tiles_kernel, dim3(tiles_w * tiles_h), dim3(64), 0, st, proj, n, xc, yc, tiles_w, tw, th,
-                       indices, counts);
+    if (!ntiles) return;
+    if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, a);
 }
 
 // scatter rank-major shard buffers [slot][tile_h][tile_w] into the raster image (rt.h:388-399)
