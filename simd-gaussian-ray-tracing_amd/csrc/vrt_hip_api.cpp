@@ -71,6 +71,13 @@ struct vrt_hip_ctx {
     DevBuf<uint32_t> ref_start, ref_count, ref_indices;
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
+    // second level: 32x32-pixel cells of the local tiles + the active/inactive queues of the render kernel
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_inactive, c_dense, c_overflow, c_counters;
+    uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
+    int lists_for_shard = -1; // sharding mode the cell lists were built for
+    bool lists_fresh = false; // the queue counters were zeroed by the list build of this very call
+    int num_cus = 256;
+    int dense_waves = 16; // waves per block in the dense kernel (tuning knob: VRT_HIP_DENSE_WAVES = 4 | 8 | 16)
     bool work_is_ref = false; // render straight from the ref lists (no tile-level cull possible)
     bool lists_dirty = true;
     DevBuf<float> xc, yc;
@@ -267,9 +274,25 @@ int ensure_device_ref_lists(vrt_hip_ctx *c)
     return VRT_HIP_OK;
 }
 
-int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
+TileLists work_lists(const vrt_hip_ctx *c);
+int rebuild_shard(vrt_hip_ctx *c);
+
+CellGrid cell_grid(const vrt_hip_ctx *c)
 {
-    if (!c->lists_dirty) return VRT_HIP_OK;
+    CellGrid g{};
+    g.cells_x = c->cells_x; g.cells_y = c->cells_y; g.cstride = c->cstride;
+    g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.inactive = c->c_inactive.p;
+    g.dense = c->c_dense.p;
+    g.n_active = c->c_counters.p; g.n_inactive = c->c_counters.p + 1; g.n_dense = c->c_counters.p + 2;
+    g.dense_next = c->c_counters.p + 3;
+    g.overflow = c->c_overflow.p; g.n_overflow = c->c_counters.p + 4;
+    g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
+    return g;
+}
+
+int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool use_shard)
+{
+    if (!c->lists_dirty && c->lists_for_shard == (int)use_shard) return VRT_HIP_OK;
     int rc = ensure_none_ref_lists(c);
     if (rc) return rc;
     const TileLists geo = tile_geometry(c);
@@ -303,7 +326,27 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
         c->work_is_ref = true;
     }
     HIPCHK(c, hipGetLastError());
+
+    // second level: cells of the tiles this context renders
+    uint32_t n_local = (uint32_t)nt;
+    const uint32_t *tile_map = nullptr;
+    if (use_shard) {
+        if ((rc = rebuild_shard(c))) return rc;
+        n_local = c->n_local; tile_map = c->tile_map.p;
+    }
+    c->cells_x = (geo.tile_w + CELL - 1) / CELL; c->cells_y = (geo.tile_h + CELL - 1) / CELL;
+    c->n_cells = n_local * c->cells_x * c->cells_y;
+    c->cstride = std::max(1u, std::min(c->n, 4096u));
+    HIPCHK(c, c->c_count.reserve(c->n_cells)); HIPCHK(c, c->c_active.reserve(c->n_cells));
+    HIPCHK(c, c->c_inactive.reserve(c->n_cells)); HIPCHK(c, c->c_dense.reserve(c->n_cells));
+    HIPCHK(c, c->c_counters.reserve(8)); HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
+    HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
+    HIPCHK(c, hipMemsetAsync(c->c_counters.p, 0, 8 * sizeof(uint32_t), st));
+    launch_build_cell_lists(tables(c), work_lists(c), cell_grid(c), a.R, tile_map, c->n_cells, refine ? 1 : 0, st);
+    HIPCHK(c, hipGetLastError());
     c->lists_dirty = false;
+    c->lists_fresh = true;
+    c->lists_for_shard = (int)use_shard;
     return VRT_HIP_OK;
 }
 
@@ -362,14 +405,14 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     HIPCHK(c, hipSetDevice(c->device));
     const TileLists geo = tile_geometry(c);
     if (geo.tile_w == 0 || geo.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
+    const bool use_shard = c->world > 1 || shard_compact;
     if ((rc = prep_frame(c, origin, st))) return rc;
-    if ((rc = build_work_lists(c, origin, st))) return rc;
+    if ((rc = build_work_lists(c, origin, st, use_shard))) return rc;
     const TileLists t = work_lists(c);
     RenderTarget o;
     o.image = d_image; o.radiance = d_rad; o.pack_flags = pack_flags;
     o.stats = c->stats_on ? c->d_stats.p : nullptr;
-    if (c->world > 1 || shard_compact) {
-        if ((rc = rebuild_shard(c))) return rc;
+    if (use_shard) {
         o.tile_map = c->tile_map.p; o.n_local_tiles = c->n_local; o.compact = shard_compact ? 1 : 0;
     } else {
         o.tile_map = nullptr; o.n_local_tiles = t.tiles_w * t.tiles_h; o.compact = 0;
@@ -378,7 +421,16 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
     c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
-    launch_render(tables(c), t, ray_gen(c, origin), o, c->exp_kind, c->erf_kind, st);
+    // persistent grid: 16 wavefronts per CU (LDS- and VGPR-limited residency), never more than there are blocks
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * 16u);
+    if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counter needs a reset
+        HIPCHK(c, hipMemsetAsync(c->c_counters.p + 3, 0, 2 * sizeof(uint32_t), st));
+    c->lists_fresh = false;
+    launch_render(tables(c), t, cell_grid(c), ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
+    // dense queue: one 16-wave workgroup per CU pulls blocks until the queue is empty (exits at once if it is)
+    launch_render_dense(tables(c), t, cell_grid(c), ray_gen(c, origin), o,
+                        (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / c->dense_waves)),
+                        c->dense_waves, c->exp_kind, c->erf_kind, st);
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;
 }
@@ -423,6 +475,12 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     vrt_hip_ctx *c = new (std::nothrow) vrt_hip_ctx();
     if (!c) return fail(nullptr, VRT_HIP_ERR_NOMEM, "create: out of host memory");
     c->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+    if (const char *e = getenv("VRT_HIP_DENSE_WAVES")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) c->dense_waves = v;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         c->d_stats.reserve(8) != hipSuccess) {
@@ -442,6 +500,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_overflow.release(); c->c_counters.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -670,7 +729,7 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     if (radiance_out) HIPCHK(c, hipMemsetAsync(c->d_rad.p, 0, npix * 16, c->stream));
     // tables / frame prep / tile lists outside the timed kernel window
     if ((rc = prep_frame(c, origin, c->stream))) return rc;
-    if ((rc = build_work_lists(c, origin, c->stream))) return rc;
+    if ((rc = build_work_lists(c, origin, c->stream, c->world > 1))) return rc;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     rc = render_common(c, origin, pack_flags, c->d_image.p, radiance_out ? c->d_rad.p : nullptr, c->stream, false);
     if (rc) return rc;
@@ -680,8 +739,10 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
     if (c->stats_on) {
-        unsigned long long st[5];
+        unsigned long long st[7];
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
+        c->last.shaded_blocks = st[5] + st[6];
+        c->last.dense_blocks = st[6];
         c->last.list_entries = st[0]; c->last.tile_entries = st[1]; c->last.overflow_blocks = st[2];
         c->last.lane_entries = st[3]; c->last.lane_max_entries = st[4];
     }
@@ -694,7 +755,7 @@ int vrt_hip_set_shard(vrt_hip_ctx *c, int rank, int world)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     if (world < 1 || rank < 0 || rank >= world) return fail(c, VRT_HIP_ERR_INVALID, "set_shard: bad rank/world");
-    c->rank = rank; c->world = world; c->shard_dirty = true;
+    c->rank = rank; c->world = world; c->shard_dirty = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
 

@@ -8,7 +8,9 @@ namespace vrtk {
 
 constexpr int BLOCK_W = 8;        // one wavefront = one 8x8 pixel block (64 rays)
 constexpr int BLOCK_H = 8;
+constexpr int CELL = 32;          // second-level cull region: 32x32 pixels = 4x4 blocks
 constexpr int PCAP = 192;         // per-block candidates cached in LDS (index + two parameter rows = 36 B each)
+constexpr int DCAP = 1024;        // per-block candidates the dense kernel keeps in LDS
 constexpr int PL = 48;            // per-lane list capacity (u8 positions into the block's candidates)
 
 // Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
@@ -30,6 +32,21 @@ struct TileLists {
     uint32_t stride;          // tile_w * tiles_w: the reference's row stride, rt.h:364-365
 };
 
+// Second-level (cell) candidate lists and the active / inactive cell queues of the persistent render kernel.
+struct CellGrid {
+    uint32_t cells_x, cells_y;       // cells per tile
+    uint32_t cstride;                // capacity of a cell's list slot
+    uint32_t *count;                 // [cells]; 0xFFFFFFFF = overflowed its slot: use the tile's list
+    uint32_t *indices;               // cell c at indices + c*cstride
+    uint32_t *active, *inactive;     // cell ids: shaded one wavefront per block / only cleared
+    uint32_t *dense;                 // cell ids with long lists: shaded one 16-wave workgroup per block
+    uint32_t *n_active, *n_inactive, *n_dense; // device counters, zeroed before build_cell_lists_kernel
+    uint32_t *dense_next;            // work counter of the dense kernel (zeroed with the others)
+    uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
+                                     // LDS slots: it hands them to the dense kernel, which runs after it
+    uint32_t dense_threshold;        // a cell whose list is longer than this goes to the dense queue
+};
+
 struct RayGen {
     const float *xs, *ys, *zs; // plane arrays (nullptr => basis mode)
     float origin[3];
@@ -48,7 +65,7 @@ struct RenderTarget {
     uint32_t n_local_tiles;
     int compact;
     unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
-                               // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list
+                               // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
 };
 
 void launch_prep_frame(const SceneTables &s, float4 *gA_out, const float origin[3], hipStream_t st);
@@ -56,8 +73,13 @@ void launch_build_static(uint32_t n, const float *mu_x, const float *mu_y, const
                          const float *ag, const float *ab, const float *aa, const float *sigma, const float *mag,
                          float cull_eps, float exp_floor_x, float4 *mu_sig, float4 *gB, float4 *gC, float4 *gD,
                          hipStream_t st);
-void launch_render(const SceneTables &s, const TileLists &t, const RayGen &r, const RenderTarget &o, int exp_kind,
-                   int erf_kind, hipStream_t st);
+void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r, const RenderTarget &o,
+                   uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
+void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                         const RenderTarget &o, uint32_t grid, int dw /* waves per block: 4, 8 or 16 */, int exp_kind,
+                         int erf_kind, hipStream_t st);
+void launch_build_cell_lists(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                             const uint32_t *tile_map, uint32_t n_cells, int refine, hipStream_t st);
 
 // per-tile list construction: tile binning (rt.cpp:29-69) and/or tile-level cull ("refine")
 struct Mat4 { float m[16]; };

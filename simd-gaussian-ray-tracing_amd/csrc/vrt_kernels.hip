@@ -328,34 +328,75 @@ __device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/
 }
 
 // ---------------------------------------------------------------------------------------------
-// Image kernel: one wavefront per 8x8 pixel block of one reference tile.
+// Image kernel: persistent wavefronts; a work item is one 8x8 pixel block (64 rays, lane = ray) of a
+// 32x32 pixel cell.  Cells whose candidate list is empty are only cleared; the others are shaded.
+// Items are dealt to waves round-robin (item = wave + k*gridDim): no queue, no atomics, every wave's
+// loop bound comes from the two cell counters the list kernels left in memory.
 // ---------------------------------------------------------------------------------------------
+struct BlockPos { uint32_t lt, t, pxt, pyt; bool inside; };
+__device__ __forceinline__ BlockPos block_of(const TileLists &T, const CellGrid &C, const RenderTarget &O, uint32_t cell,
+                                             uint32_t bi, uint32_t lane)
+{
+    BlockPos p;
+    const uint32_t cpt = C.cells_x * C.cells_y;
+    p.lt = cell / cpt;
+    const uint32_t ci = cell % cpt;
+    p.t = O.tile_map ? O.tile_map[p.lt] : p.lt;
+    const uint32_t bxi = (ci % C.cells_x) * (CELL / BLOCK_W) + (bi & 3), byi = (ci / C.cells_x) * (CELL / BLOCK_H) + (bi >> 2);
+    p.inside = bxi * BLOCK_W < T.tile_w && byi * BLOCK_H < T.tile_h; // wave-uniform
+    p.pxt = bxi * BLOCK_W + (lane & 7);
+    p.pyt = byi * BLOCK_H + (lane >> 3);
+    return p;
+}
+
 template <int EXP, int ERF, int EC>
-__global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, RayGen R, RenderTarget O,
-                                                     uint32_t blocks_x, uint32_t blocks_y)
+__global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
 {
     __shared__ uint32_t s_idx[PCAP];
     __shared__ float4 s_A[PCAP], s_B[PCAP];
     __shared__ uint8_t s_lane[PL * 64];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t bpt = blocks_x * blocks_y;
-    const uint32_t lt = blockIdx.x / bpt, b = blockIdx.x % bpt;
-    const uint32_t t = O.tile_map ? O.tile_map[lt] : lt;
-    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
-    const uint32_t bxi = b % blocks_x, byi = b / blocks_x;
-
-    // ---- this lane's pixel ----
-    const uint32_t pxt = bxi * BLOCK_W + (lane & 7), pyt = byi * BLOCK_H + (lane >> 3);
-    bool valid = pxt < T.tile_w && pyt < T.tile_h;
-    const uint32_t pxc = min(pxt, T.tile_w - 1), pyc = min(pyt, T.tile_h - 1);
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x, G = gridDim.x;
     const uint64_t npix = (uint64_t)R.width * R.height;
-    uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
-    if (pix >= npix) { valid = false; pix = npix - 1; }
-    const uint64_t out = O.compact ? ((uint64_t)lt * T.tile_h + pyt) * T.tile_w + pxt : pix;
+    const uint32_t n_inactive = *C.n_inactive, n_active = *C.n_active;
 
-    const uint32_t n_tile = T.count[t];
-    float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
-    if (n_tile != 0) { // wave-uniform: empty tiles only clear their pixels
+    // ---- clear the cells nothing can reach (4 B per ray: the only HBM traffic of most of the frame) ----
+    const uint32_t zero_px = (O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
+    for (uint32_t item = wave; item < n_inactive; item += G) { // one whole cell per item: 16 x (2 rows of 32 px)
+        const uint32_t cell = C.inactive[item];
+        const uint32_t cpt = C.cells_x * C.cells_y;
+        const uint32_t lt = cell / cpt, ci = cell % cpt;
+        const uint32_t t = O.tile_map ? O.tile_map[lt] : lt;
+        const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+        const uint32_t pxt = (ci % C.cells_x) * CELL + (lane & 31);
+#pragma unroll 4
+        for (uint32_t pass = 0; pass < CELL / 2; ++pass) {
+            const uint32_t pyt = (ci / C.cells_x) * CELL + pass * 2 + (lane >> 5);
+            const uint64_t pix = (uint64_t)(tx * T.tile_w + pxt) + (uint64_t)T.stride * (ty * T.tile_h + pyt);
+            if (pxt < T.tile_w && pyt < T.tile_h && pix < npix) {
+                const uint64_t out = O.compact ? ((uint64_t)lt * T.tile_h + pyt) * T.tile_w + pxt : pix;
+                if (O.image) O.image[out] = zero_px;
+                if (O.radiance) O.radiance[out] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+
+    // ---- shade ----
+    for (uint32_t item = wave; item < n_active * 16u; item += G) {
+        const uint32_t cell = C.active[item >> 4];
+        const BlockPos p = block_of(T, C, O, cell, item & 15u, lane);
+        if (!p.inside) continue;
+        const uint32_t tx = p.t % T.tiles_w, ty = p.t / T.tiles_w;
+        bool valid = p.pxt < T.tile_w && p.pyt < T.tile_h;
+        const uint32_t pxc = min(p.pxt, T.tile_w - 1), pyc = min(p.pyt, T.tile_h - 1);
+        uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
+        if (pix >= npix) { valid = false; pix = npix - 1; }
+        const uint64_t out = O.compact ? ((uint64_t)p.lt * T.tile_h + p.pyt) * T.tile_w + p.pxt : pix;
+
+        // the cell's candidate list (or, if it overflowed its slot, the tile's)
+        uint32_t n_list = C.count[cell];
+        const uint32_t *list = C.indices + (size_t)cell * C.cstride;
+        if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
+
         const LaneRay ray = pixel_ray(R, pix);
 
         // ---- block cone: axis = mean of the four centre rays, angle = farthest lane ----
@@ -368,16 +409,16 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
         }
         const Cone cone = make_cone(cx, cy, cz, wave_min(ray.nx * cx + ray.ny * cy + ray.nz * cz));
 
-        // ---- block cull over the tile's list (ballot compaction, order preserving) ----
-        const uint32_t *tile_list = T.indices + T.start[t];
+        // ---- block cull over the cell's list (ballot compaction, order preserving) ----
+        __syncthreads(); // previous item's LDS reads are done
         uint32_t cnt = 0;
-        for (uint32_t base = 0; base < n_tile; base += 64) {
+        for (uint32_t base = 0; base < n_list; base += 64) {
             const uint32_t k = base + lane;
             bool keep = false;
             uint32_t idx = 0;
             float4 a, bq;
-            if (k < n_tile) {
-                idx = tile_list[k];
+            if (k < n_list) {
+                idx = list[k];
                 a = S.gA[idx]; bq = S.gB[idx];
                 keep = cone_keeps(cone, a, bq);
             }
@@ -404,42 +445,210 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
             fast = __ballot(nl > PL) == 0ull;
         }
         __syncthreads();
-        if (O.stats && lane == 0) {
-            atomicAdd(&O.stats[0], (unsigned long long)(cnt <= PCAP ? cnt : n_tile));
-            atomicAdd(&O.stats[1], (unsigned long long)n_tile);
-            if (!fast) atomicAdd(&O.stats[2], 1ull);
+        if (!fast) { // hand the block to the 16-waves-per-block kernel that runs after this one
+            if (lane == 0) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | (item & 15u);
+            continue;
         }
-        if (fast) {
-            uint32_t nmax = nl;
+        if (O.stats && lane == 0) {
+            atomicAdd(&O.stats[0], (unsigned long long)cnt);
+            atomicAdd(&O.stats[1], (unsigned long long)n_list);
+            atomicAdd(&O.stats[5], 1ull);
+        }
+        uint32_t nmax = nl;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
-            if (O.stats) {
-                unsigned long long tot = nl;
+        for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+        if (O.stats) {
+            unsigned long long tot = nl;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((int)tot, off, 64);
-                if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); }
-            }
-            shade_lanes<EXP, ERF, EC>(S, s_idx, s_A, s_B, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
-        } else {
-            // candidates do not fit LDS: stream the tile's list through scalar loads (any length)
-            shade_list<EXP, ERF, 4, true>(S, tile_list, n_tile, ray, Lr, Lg, Lb, La);
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((int)tot, off, 64);
+            if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); }
+        }
+        float Lr, Lg, Lb, La;
+        shade_lanes<EXP, ERF, EC>(S, s_idx, s_A, s_B, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+        if (valid) {
+            if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
+            if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
         }
     }
+}
 
-    if (valid) {
-        if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
-        if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
+// ---------------------------------------------------------------------------------------------
+// Dense blocks (hundreds of candidates per 8x8 block: sigma of many pixels, rays of a block see the
+// same Gaussians).  One 16-wave workgroup per block: the block's candidates are culled cooperatively
+// into LDS once, the EMITTERS are dealt to the 16 waves (wave w takes chunks w, w+16, ...), every
+// wave streams all absorbers for its emitters out of LDS (wave-uniform broadcast reads), and the 16
+// partial radiances are summed in wave order -- deterministic, no float atomics.  Blocks are pulled
+// from a queue with one atomic per block (a block is >= 1e5 instructions; the counter is cold).
+// ---------------------------------------------------------------------------------------------
+template <int EXP, int ERF, int EC, int DW>
+__global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
+                                                                RenderTarget O)
+{
+    __shared__ uint32_t s_idx[DCAP];
+    __shared__ float4 s_A[DCAP], s_B[DCAP];
+    __shared__ float4 s_L[DW][64];
+    __shared__ uint32_t s_wave_cnt[DW];
+    __shared__ uint32_t s_item;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t npix = (uint64_t)R.width * R.height;
+    const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
+
+    for (;;) {
+        __syncthreads(); // everyone is done with the previous item's LDS
+        if (tid == 0) s_item = atomicAdd(C.dense_next, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= n_items) break;
+        uint32_t cell, bi;
+        if (item < n_dense16) { cell = C.dense[item >> 4]; bi = item & 15u; }
+        else { const uint32_t packed = C.overflow[item - n_dense16]; cell = packed >> 4; bi = packed & 15u; }
+        const BlockPos p = block_of(T, C, O, cell, bi, lane);
+        if (!p.inside) continue;
+        const uint32_t tx = p.t % T.tiles_w, ty = p.t / T.tiles_w;
+        bool valid = p.pxt < T.tile_w && p.pyt < T.tile_h;
+        const uint32_t pxc = min(p.pxt, T.tile_w - 1), pyc = min(p.pyt, T.tile_h - 1);
+        uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
+        if (pix >= npix) { valid = false; pix = npix - 1; }
+        const uint64_t out = O.compact ? ((uint64_t)p.lt * T.tile_h + p.pyt) * T.tile_w + p.pxt : pix;
+
+        uint32_t n_list = C.count[cell];
+        const uint32_t *list = C.indices + (size_t)cell * C.cstride;
+        if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
+
+        const LaneRay ray = pixel_ray(R, pix); // every wave holds the same 64 rays
+        float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
+        float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
+        float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
+        {
+            const float inv = 1.f / sqrtf(cx * cx + cy * cy + cz * cz);
+            cx *= inv; cy *= inv; cz *= inv;
+        }
+        const Cone cone = make_cone(cx, cy, cz, wave_min(ray.nx * cx + ray.ny * cy + ray.nz * cz));
+
+        // ---- cooperative block cull, order preserving across the 16 waves ----
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < n_list; base += DW * 64) {
+            const uint32_t k = base + tid;
+            bool keep = false;
+            uint32_t idx = 0;
+            float4 a, bq;
+            if (k < n_list) {
+                idx = list[k];
+                a = S.gA[idx]; bq = S.gB[idx];
+                keep = cone_keeps(cone, a, bq);
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+            __syncthreads();
+            uint32_t before = 0, chunk = 0;
+#pragma unroll
+            for (uint32_t wv = 0; wv < DW; ++wv) {
+                const uint32_t c = s_wave_cnt[wv];
+                before += (wv < wave) ? c : 0;
+                chunk += c;
+            }
+            const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            if (keep && pos < DCAP) { s_idx[pos] = idx; s_A[pos] = a; s_B[pos] = bq; }
+            cnt += chunk;
+            __syncthreads();
+        }
+        if (O.stats && tid == 0) {
+            atomicAdd(&O.stats[0], (unsigned long long)(cnt <= DCAP ? cnt : n_list));
+            atomicAdd(&O.stats[1], (unsigned long long)n_list);
+            if (cnt > DCAP) atomicAdd(&O.stats[2], 1ull);
+            atomicAdd(&O.stats[6], 1ull);
+        }
+
+        float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
+        if (cnt > DCAP) {
+            // does not fit LDS: one wave streams the list through scalar loads (any length)
+            if (wave == 0) shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La);
+        } else {
+            for (uint32_t i0 = wave * EC; i0 < cnt; i0 += DW * EC) {
+                float e_mubar[EC], e_sigma[EC];
+                uint32_t e_idx[EC];
+#pragma unroll
+                for (int e = 0; e < EC; ++e) {
+                    const uint32_t ii = (i0 + e < cnt) ? (i0 + e) : i0;
+                    e_idx[e] = __builtin_amdgcn_readfirstlane(s_idx[ii]);
+                    const float4 a = s_A[ii];
+                    e_mubar[e] = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+                    e_sigma[e] = uload(S.gD, e_idx[e]).x;
+                }
+                float acc[EC][5];
+#pragma unroll
+                for (int e = 0; e < EC; ++e)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) acc[e][k] = 0.f;
+
+                float4 a = s_A[0], b = s_B[0];
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const float4 ca = a, cb = b;
+                    if (j + 1 < cnt) { a = s_A[j + 1]; b = s_B[j + 1]; }
+                    const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+                    const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+                    const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
+                    const float m = mubar * cb.x;
+                    const float E = verf<ERF>(-m);
+#pragma unroll
+                    for (int e = 0; e < EC; ++e) {
+                        const float base = __builtin_fmaf(e_mubar[e], cb.x, -m);
+                        const float step = e_sigma[e] * cb.x;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const float x = __builtin_fmaf((float)(k - 4), step, base);
+                            acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EC; ++e) {
+                    if (i0 + e < cnt) {
+                        const float4 ms = uload(S.mu_sig, e_idx[e]);
+                        const float inv2s2 = uload(S.gB, e_idx[e]).y;
+                        const float q = uload(S.gD, e_idx[e]).y;
+                        float inner = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[e]);
+                            const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
+                            const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
+                            const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
+                            const float dd = dot3_ref(px, py, pz, px, py, pz);
+                            const float Tk = vexp<EXP>(acc[e][k]);
+                            inner = __builtin_fmaf(q * vexp<EXP>(-(dd * inv2s2)), Tk, inner);
+                        }
+                        const float4 alb = uload(S.gC, e_idx[e]);
+                        Lr = __builtin_fmaf(alb.x, inner, Lr);
+                        Lg = __builtin_fmaf(alb.y, inner, Lg);
+                        Lb = __builtin_fmaf(alb.z, inner, Lb);
+                        La = __builtin_fmaf(alb.w, inner, La);
+                    }
+                }
+            }
+        }
+        // ---- sum the waves' partial radiances in wave order ----
+        s_L[wave][lane] = make_float4(Lr, Lg, Lb, La);
+        __syncthreads();
+        if (wave == 0 && valid) {
+            float4 sum = s_L[0][lane];
+#pragma unroll
+            for (int w = 1; w < DW; ++w) {
+                const float4 v = s_L[w][lane];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            if (O.image) O.image[out] = pack_pixel(sum.x, sum.y, sum.z, sum.w, O.pack_flags);
+            if (O.radiance) O.radiance[out] = sum;
+        }
     }
 }
 
 template <int EXP, int ERF>
-static void launch_render_t(const SceneTables &s, const TileLists &t, const RayGen &r, const RenderTarget &o,
-                            hipStream_t st)
+static void launch_render_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                            const RenderTarget &o, uint32_t grid, hipStream_t st)
 {
-    const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
-    const uint64_t nblocks = (uint64_t)o.n_local_tiles * bx * by;
-    if (nblocks == 0) return;
-    hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3((uint32_t)nblocks), dim3(64), 0, st, s, t, r, o, bx, by);
+    if (grid == 0) return;
+    hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
 }
 
 #define VRT_DISPATCH_EXP_ERF(FN, ...)                                                              \
@@ -456,10 +665,25 @@ static void launch_render_t(const SceneTables &s, const TileLists &t, const RayG
     default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
     }
 
-void launch_render(const SceneTables &s, const TileLists &t, const RayGen &r, const RenderTarget &o, int exp_kind,
-                   int erf_kind, hipStream_t st)
+void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r, const RenderTarget &o,
+                   uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
-    VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, r, o, st);
+    VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, st);
+}
+
+template <int EXP, int ERF>
+static void launch_render_dense_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                                  const RenderTarget &o, uint32_t grid, int dw, hipStream_t st)
+{
+    if (grid == 0) return;
+    if (dw == 16) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
+    else if (dw == 8) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 8>), dim3(grid), dim3(512), 0, st, s, t, c, r, o);
+    else hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 4>), dim3(grid), dim3(256), 0, st, s, t, c, r, o);
+}
+void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                         const RenderTarget &o, uint32_t grid, int dw, int exp_kind, int erf_kind, hipStream_t st)
+{
+    VRT_DISPATCH_EXP_ERF(launch_render_dense_t, s, t, c, r, o, grid, dw, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -621,6 +845,89 @@ void launch_build_tile_lists(const BinArgs &a, bool from_list, uint32_t ntiles, 
     if (!ntiles) return;
     if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second level: one wavefront per 32x32 pixel cell filters its tile's list with the cell's cone.
+// 16 cells share a 1024-thread workgroup so that filing the cells as active (non-empty list) or
+// inactive (to be cleared) costs two atomics per 16 cells -- one hot counter word serialises at
+// ~11 ns per returning atomic, which 4096 single-cell atomics would turn into the longest kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
+                                                                 const uint32_t *tile_map, uint32_t n_cells, int refine)
+{
+    __shared__ uint32_t s_flag[16];  // 0 = inactive, 1 = active (sparse), 3 = active (dense), 2 = no such cell
+    __shared__ uint32_t s_base[3];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t cell = blockIdx.x * 16 + wave;
+    uint32_t total = 0;
+    if (cell < n_cells) {
+        const uint32_t cpt = C.cells_x * C.cells_y;
+        const uint32_t lt = cell / cpt, ci = cell % cpt;
+        const uint32_t t = tile_map ? tile_map[lt] : lt;
+        const uint32_t n_in = T.count[t];
+        if (n_in) {
+            const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+            const uint32_t x0 = (ci % C.cells_x) * CELL, y0 = (ci / C.cells_x) * CELL;
+            const uint32_t x1 = min(x0 + CELL, T.tile_w) - 1, y1 = min(y0 + CELL, T.tile_h) - 1;
+            Cone cone = {};
+            if (refine) {
+                const uint64_t npix = (uint64_t)R.width * R.height;
+                auto at = [&](uint32_t x, uint32_t y) {
+                    uint64_t pix = (uint64_t)(tx * T.tile_w + x) + (uint64_t)T.stride * (ty * T.tile_h + y);
+                    if (pix >= npix) pix = npix - 1;
+                    return pixel_ray(R, pix);
+                };
+                // lanes 0..3 take a corner each, everyone the centre
+                const LaneRay c = at((x0 + x1 + 1) / 2, (y0 + y1 + 1) / 2);
+                const LaneRay k = at((lane & 1) ? x1 : x0, (lane & 2) ? y1 : y0);
+                cone = make_cone(c.nx, c.ny, c.nz, wave_min(k.nx * c.nx + k.ny * c.ny + k.nz * c.nz));
+                cone.sin_t += 1e-4f; // the centre pixel is up to half a pixel off the rectangle's centre
+            }
+            const uint32_t *in_list = T.indices + T.start[t];
+            uint32_t *out = C.indices + (size_t)cell * C.cstride;
+            for (uint32_t base = 0; base < n_in; base += 64) {
+                const uint32_t k = base + lane;
+                bool keep = false;
+                uint32_t idx = 0;
+                if (k < n_in) {
+                    idx = in_list[k];
+                    keep = refine ? cone_keeps(cone, S.gA[idx], S.gB[idx]) : true;
+                }
+                const unsigned long long mask = __ballot(keep);
+                const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                if (keep && pos < C.cstride) out[pos] = idx;
+                total += (uint32_t)__popcll(mask);
+            }
+        }
+        if (lane == 0) C.count[cell] = total > C.cstride ? 0xFFFFFFFFu : total;
+    }
+    if (lane == 0) s_flag[wave] = cell < n_cells ? (total ? (total > C.dense_threshold ? 3u : 1u) : 0u) : 2u;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t na = 0, ni = 0, nd = 0;
+        for (int w = 0; w < 16; ++w) { na += s_flag[w] == 1u; ni += s_flag[w] == 0u; nd += s_flag[w] == 3u; }
+        s_base[0] = na ? atomicAdd(C.n_active, na) : 0u;
+        s_base[1] = ni ? atomicAdd(C.n_inactive, ni) : 0u;
+        s_base[2] = nd ? atomicAdd(C.n_dense, nd) : 0u;
+    }
+    __syncthreads();
+    if (lane == 0 && cell < n_cells) {
+        uint32_t before = 0;
+        const uint32_t mine = s_flag[wave];
+        for (uint32_t w = 0; w < wave; ++w) before += s_flag[w] == mine;
+        if (mine == 1u) C.active[s_base[0] + before] = cell;
+        else if (mine == 3u) C.dense[s_base[2] + before] = cell;
+        else C.inactive[s_base[1] + before] = cell;
+    }
+}
+
+void launch_build_cell_lists(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                             const uint32_t *tile_map, uint32_t n_cells, int refine, hipStream_t st)
+{
+    if (!n_cells) return;
+    hipLaunchKernelGGL(build_cell_lists_kernel, dim3((n_cells + 15) / 16), dim3(1024), 0, st, s, t, c, r, tile_map,
+                       n_cells, refine);
 }
 
 // scatter rank-major shard buffers [slot][tile_h][tile_w] into the raster image (rt.h:388-399)
