@@ -304,6 +304,8 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     a.R = ray_gen(c, origin);
     a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
     c->work_is_ref = false;
+    HIPCHK(c, c->c_counters.reserve(8));
+    a.zero8 = c->c_counters.p;
     if (c->tile_mode == TILES_DEVICE) {
         if (c->grid_n != c->n) { // the scene was replaced after tile_gaussians(): re-stride the list buffers
             HIPCHK(c, hipStreamSynchronize(st));
@@ -311,6 +313,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
             a = bin_args(c);
             a.refine = refine ? 1 : 0; a.R = ray_gen(c, origin);
             a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
+            a.zero8 = c->c_counters.p;
         }
         a.out_start = c->w_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
         launch_build_tile_lists(a, false, (uint32_t)nt, st);
@@ -324,6 +327,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         launch_build_tile_lists(a, true, (uint32_t)nt, st);
     } else {
         c->work_is_ref = true;
+        HIPCHK(c, hipMemsetAsync(c->c_counters.p, 0, 8 * sizeof(uint32_t), st)); // no list kernel ran to clear them
     }
     HIPCHK(c, hipGetLastError());
 
@@ -339,9 +343,8 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     c->cstride = std::max(1u, std::min(c->n, 4096u));
     HIPCHK(c, c->c_count.reserve(c->n_cells)); HIPCHK(c, c->c_active.reserve(c->n_cells));
     HIPCHK(c, c->c_inactive.reserve(c->n_cells)); HIPCHK(c, c->c_dense.reserve(c->n_cells));
-    HIPCHK(c, c->c_counters.reserve(8)); HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
+    HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
-    HIPCHK(c, hipMemsetAsync(c->c_counters.p, 0, 8 * sizeof(uint32_t), st));
     launch_build_cell_lists(tables(c), work_lists(c), cell_grid(c), a.R, tile_map, c->n_cells, refine ? 1 : 0, st);
     HIPCHK(c, hipGetLastError());
     c->lists_dirty = false;

@@ -100,6 +100,7 @@ struct BinArgs {
     // output: list of tile t at out_indices[out_start[t] ...], length out_count[t]
     const uint32_t *out_start;
     uint32_t *out_indices, *out_count;
+    uint32_t *zero8;                 // nullable: 8 queue counters this launch clears for the kernels after it
 };
 void launch_build_tile_lists(const BinArgs &a, bool from_list, uint32_t ntiles, hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t n_slots,

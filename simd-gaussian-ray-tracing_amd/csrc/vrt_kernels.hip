@@ -759,6 +759,7 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P)
     __shared__ uint32_t s_wave_cnt[16];
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tx = t % P.tiles_w, ty = t / P.tiles_w;
+    if (P.zero8 && t == 0 && tid < 8) P.zero8[tid] = 0; // saves a 5 us memset node per frame
 
     // (b) tile cone from the centre and the four corner pixels of the tile (pinhole rays: the
     // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)

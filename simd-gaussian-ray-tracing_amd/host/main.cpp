@@ -1,0 +1,189 @@
+// volumetric-ray-tracer -- MI355X drop-in for the reference CLI's quiet path
+// (src/volumetric-ray-tracer/main.cpp, run with -q: no viewer).  Same flags, same scene producers,
+// same per-frame loop (tile -> render -> PNG -> timing line -> orbit step), same output lines
+// ("TIME: <ms> ms" / "AVG. TIME: <ms> ms (<n> frames)", main.cpp:308-315) so that runtimes.sh /
+// gen-gif.sh keep working.  Rendering goes through the C ABI of libvrt_hip.so; the interactive
+// Vulkan/ImGui viewer of the reference is out of scope, so -q is implied.
+#include <getopt.h>
+#include <time.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vrt/vrt.hpp"
+#include "png_writer.hpp"
+
+#define HELP_MSG "Usage: volumetric-ray-tracer [options]\n"\
+    "\nOptions:\n"\
+    "\t--help:                                 Show this help message.\n"\
+    "\t--file <file>, -f <file>:               Load gaussians as verticies from <file> (.obj).\n"\
+    "\t--output <file>, -o <file>:             Write image to <file> as in PNG format.\n"\
+    "\t--grid <dim=4>, -g <dim=4>:             Render a grid of <dim>x<dim> gaussians.\n"\
+    "\t--width <width>, -w <width>:            Set image width to <width>. Set height to <width> too if --height is not set.\n"\
+    "\t--height <height>, -h <height>:         Set image height to <height>. Set width to <height> too if --width is not set\n"\
+    "\t--with-threads <count>, -t <count>:     Accepted for compatibility; the GPU grid replaces the thread pool.\n"\
+    "\t--quiet, -q:                            Accepted for compatibility; there is no viewer, -q is always on.\n"\
+    "\t--frames <count>:                       Render <count> frames.\n"\
+    "\t--tiles <count>:                        Split the image into <count> tiles vertically and horizontally.\n"\
+    "\t--rotation <rot>, -r <rot>:             Changes the viewing angle by <rot>/<frames> every frame.\n"\
+    "\t--initial-rotation <rot>, -i <rot>:     Sets the initial rotation to <rot>.\n"\
+    "\t--camaera-offset <offset>, -c <offset>: Set the position of the camera along the Z-Axis to <offset>.\n"\
+    "\t--focal-length <focal-length>:          Set the focal length of the camera to <focal-length>.\n"\
+    "\t--mode <mode>, -m <mode>:               Set the rendering mode to <mode> (1-4 without, 5-8 with tiling;\n"\
+    "\t                                        selects the packing convention and Exp/Erf pair of that mode).\n"\
+    "\t--plane-arrays:                         Feed the projection-plane arrays like the reference (default: in-kernel rays).\n"\
+    "\t--cull-eps <eps>:                       Culling threshold (default 1e-9; 0 = the reference's full sum).\n"
+
+struct cmd_args_t { // main.cpp:54-184
+    u64 w = (u64)-1, h = (u64)-1;
+    u64 grid_dim = 4;
+    char *outfile = nullptr, *infile = nullptr;
+    bool use_grid = false;
+    u64 thread_count = 1, nr_frames = 1, tiles = 16, mode = 8;
+    f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f;
+    bool plane_arrays = false;
+    cmd_args_t(int argc, char **argv)
+    {
+        static struct option opts[] = {
+            { "grid", optional_argument, NULL, 'g' }, { "file", required_argument, NULL, 'f' },
+            { "output", required_argument, NULL, 'o' }, { "width", required_argument, NULL, 'w' },
+            { "height", required_argument, NULL, 'h' }, { "with-threads", required_argument, NULL, 't' },
+            { "quiet", no_argument, NULL, 'q' }, { "tiles", required_argument, NULL, 'l' },
+            { "mode", required_argument, NULL, 'm' }, { "frames", required_argument, NULL, 's' },
+            { "rotation", required_argument, NULL, 'r' }, { "initial-rotation", required_argument, NULL, 'i' },
+            { "camera-offset", required_argument, NULL, 'c' }, { "focal-length", required_argument, NULL, 0xfe },
+            { "help", no_argument, NULL, 0xff }, { "plane-arrays", no_argument, NULL, 0xfd },
+            { "cull-eps", required_argument, NULL, 0xfc }, { NULL, 0, NULL, 0 }
+        };
+        int lidx;
+        for (;;) {
+            const int c = getopt_long(argc, argv, "r:m:qw:o:f:g:h:t:c:i:", opts, &lidx);
+            if (c == -1) break;
+            switch (c) {
+            case 'g': use_grid = true; if (optarg) grid_dim = strtoul(optarg, NULL, 10); break;
+            case 'f': infile = optarg; break;
+            case 'o': outfile = optarg; break;
+            case 'w': w = strtoul(optarg, NULL, 10); if (h == (u64)-1) h = w; break;
+            case 'h': h = strtoul(optarg, NULL, 10); if (w == (u64)-1) w = h; break;
+            case 't': thread_count = strtoul(optarg, NULL, 10); break;
+            case 'q': break;
+            case 'l': tiles = strtoul(optarg, NULL, 10); break;
+            case 's': nr_frames = strtoul(optarg, NULL, 10); break;
+            case 'r': rot = strtof(optarg, NULL); break;
+            case 'i': inital_rot = strtof(optarg, NULL); break;
+            case 'c': camera_offset = strtof(optarg, NULL); break;
+            case 0xff: fputs(HELP_MSG, stdout); exit(EXIT_SUCCESS);
+            case 0xfe: focal_length = strtof(optarg, NULL); break;
+            case 0xfd: plane_arrays = true; break;
+            case 0xfc: cull_eps = strtof(optarg, NULL); break;
+            case 'm': mode = strtoul(optarg, NULL, 10); if (mode < 1 || mode > 8) mode = 8; break;
+            default: break;
+            }
+        }
+        if (w == (u64)-1) w = 256;
+        if (h == (u64)-1) h = 256;
+        if (use_grid && infile != nullptr) use_grid = false; // main.cpp:182: a file overrides the grid
+        if (tiles == 0) tiles = 1;
+        if (nr_frames == 0) nr_frames = 1;
+    }
+};
+
+static double now_ms()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+int main(int argc, char **argv)
+{
+    cmd_args_t cmd(argc, argv);
+    std::vector<vrt::gaussian_t> gaussians;
+    if (cmd.infile != nullptr) {
+        gaussians = read_from_obj(cmd.infile);
+    } else { // main.cpp:194-205
+        const u8 grid_dim = (u8)cmd.grid_dim;
+        for (u8 i = 0; i < grid_dim; ++i)
+            for (u8 j = 0; j < grid_dim; ++j)
+                gaussians.push_back(vrt::gaussian_t{
+                    { 1.f - (i * grid_dim + j) / (f32)(grid_dim * grid_dim), 0.f, 0.f + (i * grid_dim + j) / (f32)(grid_dim * grid_dim), 1.f },
+                    { -1.f + 1.f / grid_dim + i * 1.f / (grid_dim / 2.f), -1.f + 1.f / grid_dim + j * 1.f / (grid_dim / 2.f), 1.f },
+                    1.f / (2 * grid_dim), 1.f });
+    }
+
+    // mode table (main.cpp:150-177, 269-294): tiling, packing, Exp/Erf
+    const bool use_tiling = cmd.mode >= 5;
+    const u64 base_mode = (cmd.mode - 1) % 4 + 1;
+    int pack = VRT_PACK_TRUNC | VRT_ALPHA_OPAQUE, ek = VRT_EXP_VCL, rk = VRT_ERF_AS;
+    if (base_mode == 1) { ek = VRT_EXP_LIBM; rk = VRT_ERF_LIBM; }
+    if (base_mode == 4) pack = VRT_PACK_ROUND | (use_tiling ? VRT_ALPHA_COMPUTED : VRT_ALPHA_OPAQUE);
+
+    vrt_hip_ctx *ctx = nullptr;
+    const char *dev = getenv("VRT_HIP_DEVICE");
+    if (vrt_hip_create(dev ? atoi(dev) : 0, &ctx) != VRT_HIP_OK) {
+        fprintf(stderr, "[ ERROR ]\t%s\n", vrt_hip_last_error(nullptr));
+        return EXIT_FAILURE;
+    }
+    auto chk = [&](int rc, const char *what) {
+        if (rc != VRT_HIP_OK) { fprintf(stderr, "[ ERROR ]\t%s: %s\n", what, vrt_hip_last_error(ctx)); exit(EXIT_FAILURE); }
+    };
+    chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians");
+    chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options");
+
+    const u64 width = cmd.w, height = cmd.h;
+    std::vector<u32> image(width * height);
+
+    // main.cpp:247-255
+    vrt::camera_t cam({ 0.f, 0.f, cmd.camera_offset }, { 0.f, 1.f, 0.f }, { 0.f, 0.f, 1.f }, -90.f, 0.f,
+                      cmd.plane_arrays ? width : 1, cmd.plane_arrays ? height : 1, cmd.focal_length);
+    f32 angle = -90.f;
+    cam.orbit(cmd.inital_rot);
+    angle -= cmd.inital_rot;
+    cam.turn(angle, 0.f);
+
+    f32 total_time = 0.f;
+    for (u64 frames = 1;; ++frames) {
+        const f32 origin[3] = { cam.position[0], cam.position[1], cam.position[2] };
+        // rays for this camera pose (the reference rebuilds the plane arrays in cam.turn(), outside its timers)
+        if (cmd.plane_arrays)
+            chk(vrt_hip_set_plane(ctx, (u32)width, (u32)height, cam.projection_plane.xs.data(), cam.projection_plane.ys.data(),
+                                  cam.projection_plane.zs.data()), "set_plane");
+        else
+            chk(vrt_hip_set_camera(ctx, (u32)width, (u32)height, cam.position.data(), cam.right.data(), cam.up.data(),
+                                   cam.front.data(), cam.focal_length), "set_camera");
+
+        double t0 = now_ms();
+        if (use_tiling) chk(vrt_hip_tile_gaussians_device(ctx, 2.f / cmd.tiles, 2.f / cmd.tiles, cam.view_matrix.data(), nullptr), "tile_gaussians");
+        else chk(vrt_hip_clear_tiles(ctx), "clear_tiles");
+        const f32 tiling_time = (f32)(now_ms() - t0);
+
+        t0 = now_ms();
+        chk(vrt_hip_render(ctx, origin, pack, image.data(), nullptr), "render");
+        const f32 draw_time = (f32)(now_ms() - t0);
+
+        if (cmd.outfile != nullptr) { // main.cpp:299-307: <stem>_<frame>.<ext> when more than one frame
+            const std::string of(cmd.outfile);
+            const size_t dot = of.find_last_of('.');
+            const std::string stem = of.substr(0, dot), ext = dot == std::string::npos ? "png" : of.substr(dot + 1);
+            const std::string path = cmd.nr_frames > 1 ? stem + "_" + std::to_string(frames) + "." + ext : stem + "." + ext;
+            if (!png::write_rgba(path.c_str(), (u32)width, (u32)height, image.data(), width * 4))
+                fprintf(stderr, "[ ERROR ]\tcould not write %s\n", path.c_str());
+        }
+        if (cmd.nr_frames == 1) printf("TIME: %g ms\n", draw_time + tiling_time);
+        total_time += draw_time + tiling_time;
+        if (cmd.nr_frames == frames) {
+            if (cmd.nr_frames > 1) printf("AVG. TIME: %g ms (%llu frames)\n", total_time / cmd.nr_frames, (unsigned long long)cmd.nr_frames);
+            break;
+        }
+        // main.cpp:329-334
+        const f32 angle_change = cmd.rot / cmd.nr_frames;
+        cam.orbit(angle_change);
+        angle -= angle_change;
+        cam.turn(angle, 0.f);
+    }
+    vrt_hip_destroy(ctx);
+    return EXIT_SUCCESS;
+}
