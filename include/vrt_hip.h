@@ -159,6 +159,11 @@ typedef struct {
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */
 int vrt_hip_enable_stats(vrt_hip_ctx *ctx, int on);
+/* Kernel timing for roofline reports: while enabled, every render launch is bracketed with HIP events ON THE
+ * STREAM IT RUNS ON (ring of the last 512 launches).  get() waits for them and returns the mean duration of
+ * the one-wave-per-block render kernel, of the 16-waves-per-block (dense) kernel and of the list kernels. */
+int vrt_hip_enable_kernel_timing(vrt_hip_ctx *ctx, int on);
+int vrt_hip_get_kernel_timing(vrt_hip_ctx *ctx, double *render_ms, double *dense_ms, double *lists_ms, uint64_t *launches);
 
 #ifdef __cplusplus
 }

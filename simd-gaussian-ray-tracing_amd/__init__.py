@@ -75,6 +75,9 @@ SYMBOLS = {
     "vrt_hip_eval_exp": (C.c_int, [_vp, C.c_int, _f32p, C.c_size_t, _f32p]),
     "vrt_hip_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "vrt_hip_enable_stats": (C.c_int, [_vp, C.c_int]),
+    "vrt_hip_enable_kernel_timing": (C.c_int, [_vp, C.c_int]),
+    "vrt_hip_get_kernel_timing": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_uint64)]),
 }
 
 
@@ -274,6 +277,16 @@ class Renderer:
 
     def enable_stats(self, on=True):
         self._chk(self._L.vrt_hip_enable_stats(self._h, int(on)), "enable_stats")
+
+    def enable_kernel_timing(self, on=True):
+        self._chk(self._L.vrt_hip_enable_kernel_timing(self._h, int(on)), "enable_kernel_timing")
+
+    def kernel_timing(self):
+        """Mean HIP-event durations (ms) of the render kernel, the dense kernel and the list kernels."""
+        r, d, l, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint64()
+        self._chk(self._L.vrt_hip_get_kernel_timing(self._h, C.byref(r), C.byref(d), C.byref(l), C.byref(n)),
+                  "get_kernel_timing")
+        return dict(render_ms=r.value, dense_ms=d.value, lists_ms=l.value, launches=n.value)
 
     def stats(self):
         s = Stats()

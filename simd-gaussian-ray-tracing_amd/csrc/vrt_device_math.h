@@ -192,6 +192,16 @@ __device__ __forceinline__ float verf(float x)
     else if constexpr (ERF == VRT_ERF_TAYLOR) return erf_taylor(x);
     else return erff(x);
 }
+// |x| from which the variant returns EXACTLY +-1.0f (used to skip saturated terms without changing a bit):
+//   A&S: 1 - rcp(p^4) rounds to 1 once p^4 > 2^25, i.e. |x| >= 5.46; erff: erfc(4.2) = 2.9e-9 << 2^-25;
+//   the splines and the Taylor form clamp explicitly (approx.cpp:11,24,47,75-76).
+template <int ERF>
+__host__ __device__ constexpr float erf_saturation()
+{
+    return ERF == VRT_ERF_AS ? 5.5f : ERF == VRT_ERF_SPLINE ? 3.1f : ERF == VRT_ERF_SPLINE_MIRROR ? 2.9f
+         : ERF == VRT_ERF_TAYLOR ? 2.0f : 4.2f;
+}
+
 // A * erf(x) -- the hot-loop form
 template <int ERF>
 __device__ __forceinline__ float verf_weighted(float x, float A)

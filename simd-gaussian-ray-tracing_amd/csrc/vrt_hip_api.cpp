@@ -109,6 +109,11 @@ struct vrt_hip_ctx {
     DevBuf<unsigned long long> d_stats;
     bool stats_on = false;
     vrt_hip_stats last{};
+    // kernel timing ring (vrt_hip_enable_kernel_timing)
+    static constexpr int TIMING_RING = 512;
+    bool timing_on = false;
+    std::vector<hipEvent_t> tev; // 4 per slot: before lists, before render, after render, after dense
+    uint64_t timing_count = 0;
 };
 
 namespace {
@@ -409,6 +414,15 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     const TileLists geo = tile_geometry(c);
     if (geo.tile_w == 0 || geo.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
     const bool use_shard = c->world > 1 || shard_compact;
+    hipEvent_t *tev = nullptr;
+    if (c->timing_on) {
+        if (c->tev.empty()) {
+            c->tev.resize(4 * vrt_hip_ctx::TIMING_RING);
+            for (auto &e : c->tev) HIPCHK(c, hipEventCreate(&e));
+        }
+        tev = &c->tev[4 * (c->timing_count % vrt_hip_ctx::TIMING_RING)];
+        HIPCHK(c, hipEventRecord(tev[0], st));
+    }
     if ((rc = prep_frame(c, origin, st))) return rc;
     if ((rc = build_work_lists(c, origin, st, use_shard))) return rc;
     const TileLists t = work_lists(c);
@@ -429,11 +443,14 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counter needs a reset
         HIPCHK(c, hipMemsetAsync(c->c_counters.p + 3, 0, 2 * sizeof(uint32_t), st));
     c->lists_fresh = false;
+    if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
     launch_render(tables(c), t, cell_grid(c), ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
+    if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
     // dense queue: one 16-wave workgroup per CU pulls blocks until the queue is empty (exits at once if it is)
     launch_render_dense(tables(c), t, cell_grid(c), ray_gen(c, origin), o,
-                        (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / c->dense_waves)),
+                        (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16))),
                         c->dense_waves, c->exp_kind, c->erf_kind, st);
+    if (tev) { HIPCHK(c, hipEventRecord(tev[3], st)); ++c->timing_count; }
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;
 }
@@ -482,7 +499,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
     if (const char *e = getenv("VRT_HIP_DENSE_WAVES")) {
         const int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16) c->dense_waves = v;
+        if (v == 4 || v == 8 || v == 16 || v == 17) c->dense_waves = v; // 17 = 16 waves without saturation skipping (A/B)
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -506,6 +523,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_overflow.release(); c->c_counters.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release();
+    for (auto &e : c->tev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -891,6 +909,36 @@ int vrt_hip_enable_stats(vrt_hip_ctx *c, int on)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     c->stats_on = on != 0;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_enable_kernel_timing(vrt_hip_ctx *c, int on)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    c->timing_on = on != 0;
+    if (on) c->timing_count = 0;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_get_kernel_timing(vrt_hip_ctx *c, double *render_ms, double *dense_ms, double *lists_ms, uint64_t *launches)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = std::min<uint64_t>(c->timing_count, vrt_hip_ctx::TIMING_RING);
+    double sr = 0, sd = 0, sl = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        hipEvent_t *e = &c->tev[4 * i];
+        HIPCHK(c, hipEventSynchronize(e[3]));
+        float a = 0, b = 0, d = 0;
+        HIPCHK(c, hipEventElapsedTime(&a, e[0], e[1]));
+        HIPCHK(c, hipEventElapsedTime(&b, e[1], e[2]));
+        HIPCHK(c, hipEventElapsedTime(&d, e[2], e[3]));
+        sl += a; sr += b; sd += d;
+    }
+    if (render_ms) *render_ms = n ? sr / n : 0.0;
+    if (dense_ms) *dense_ms = n ? sd / n : 0.0;
+    if (lists_ms) *lists_ms = n ? sl / n : 0.0;
+    if (launches) *launches = n;
     return VRT_HIP_OK;
 }
 

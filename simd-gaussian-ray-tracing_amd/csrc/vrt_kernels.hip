@@ -480,17 +480,20 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
 // partial radiances are summed in wave order -- deterministic, no float atomics.  Blocks are pulled
 // from a queue with one atomic per block (a block is >= 1e5 instructions; the counter is cold).
 // ---------------------------------------------------------------------------------------------
-template <int EXP, int ERF, int EC, int DW>
+template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
 __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
                                                                 RenderTarget O)
 {
-    __shared__ uint32_t s_idx[DCAP];
-    __shared__ float4 s_A[DCAP], s_B[DCAP];
+    __shared__ uint32_t s_idx0[DCAP], s_idx[DCAP];   // "0": in list order; the others: sorted by depth
+    __shared__ float4 s_A0[DCAP], s_B0[DCAP], s_A[DCAP], s_B[DCAP];
+    __shared__ float s_key[DCAP];
     __shared__ float4 s_L[DW][64];
     __shared__ uint32_t s_wave_cnt[DW];
     __shared__ uint32_t s_item;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t npix = (uint64_t)R.width * R.height;
+    constexpr float SAT = erf_saturation<ERF>();
+    constexpr float SAT_M = SAT + 1e-3f; // the range bounds are re-associated forms of the arguments: keep a margin
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
 
     for (;;) {
@@ -548,10 +551,27 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                 chunk += c;
             }
             const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            if (keep && pos < DCAP) { s_idx[pos] = idx; s_A[pos] = a; s_B[pos] = bq; }
+            if (keep && pos < DCAP) {
+                s_idx0[pos] = idx; s_A0[pos] = a; s_B0[pos] = bq;
+                s_key[pos] = a.x * cone.cx + a.y * cone.cy + a.z * cone.cz; // depth along the block's axis
+            }
             cnt += chunk;
             __syncthreads();
         }
+        // ---- sort the candidates by depth (rank sort: every thread ranks one candidate against all keys) so
+        //      that the emitters of a chunk are neighbours in depth and whole absorbers saturate for them ----
+        if (cnt <= DCAP) {
+            for (uint32_t i = tid; i < cnt; i += DW * 64) {
+                const float ki = s_key[i];
+                uint32_t r = 0;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float kk = s_key[k];
+                    r += (kk < ki || (kk == ki && k < i)) ? 1u : 0u;
+                }
+                s_idx[r] = s_idx0[i]; s_A[r] = s_A0[i]; s_B[r] = s_B0[i];
+            }
+        }
+        __syncthreads();
         if (O.stats && tid == 0) {
             atomicAdd(&O.stats[0], (unsigned long long)(cnt <= DCAP ? cnt : n_list));
             atomicAdd(&O.stats[1], (unsigned long long)n_list);
@@ -581,14 +601,30 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
 #pragma unroll
                     for (int k = 0; k < 5; ++k) acc[e][k] = 0.f;
 
+                // Saturation: Erf(x) is EXACTLY +-1 in fp32 for |x| >= SAT.  An absorber j in front of the camera
+                // (m_j >= SAT => E_j = -1) whose Erf argument is <= -SAT at every sample of every emitter of the chunk
+                // on every ray of the block adds exactly A_j*(-1 - -1) = 0: skipped before even forming A_j.  One whose
+                // arguments are all >= SAT adds exactly -2 A_j to all 5*EC sums: one fma into `common`.
+                float common = 0.f;
+                float s_max = -INFINITY, s_min = INFINITY; // this ray's sample range over the chunk's emitters
+#pragma unroll
+                for (int e = 0; e < EC; ++e) {
+                    s_max = fmaxf(s_max, e_mubar[e]);
+                    s_min = fminf(s_min, __builtin_fmaf(-4.f, e_sigma[e], e_mubar[e]));
+                }
                 float4 a = s_A[0], b = s_B[0];
                 for (uint32_t j = 0; j < cnt; ++j) {
                     const float4 ca = a, cb = b;
                     if (j + 1 < cnt) { a = s_A[j + 1]; b = s_B[j + 1]; }
                     const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+                    const float m = mubar * cb.x;
+                    // argument range over the chunk's samples on this ray: [(s_min - mubar_j) r_j, (s_max - mubar_j) r_j]
+                    const float hi = __builtin_fmaf(s_max, cb.x, -m), lo = __builtin_fmaf(s_min, cb.x, -m);
+                    const bool front = m >= SAT;
+                    if (SKIP && __all(front && hi <= -SAT_M)) continue;
                     const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
                     const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
-                    const float m = mubar * cb.x;
+                    if (SKIP && __all(front && lo >= SAT_M)) { common = __builtin_fmaf(A, -2.f, common); continue; }
                     const float E = verf<ERF>(-m);
 #pragma unroll
                     for (int e = 0; e < EC; ++e) {
@@ -615,7 +651,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                             const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
                             const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
                             const float dd = dot3_ref(px, py, pz, px, py, pz);
-                            const float Tk = vexp<EXP>(acc[e][k]);
+                            const float Tk = vexp<EXP>(acc[e][k] + common);
                             inner = __builtin_fmaf(q * vexp<EXP>(-(dd * inv2s2)), Tk, inner);
                         }
                         const float4 alb = uload(S.gC, e_idx[e]);
@@ -676,7 +712,8 @@ static void launch_render_dense_t(const SceneTables &s, const TileLists &t, cons
                                   const RenderTarget &o, uint32_t grid, int dw, hipStream_t st)
 {
     if (grid == 0) return;
-    if (dw == 16) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
+    if (dw == 17) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16, false>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
+    else if (dw == 16) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
     else if (dw == 8) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 8>), dim3(grid), dim3(512), 0, st, s, t, c, r, o);
     else hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 4>), dim3(grid), dim3(256), 0, st, s, t, c, r, o);
 }

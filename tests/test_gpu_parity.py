@@ -284,3 +284,44 @@ def test_sharded_render_assembles_to_full_frame(pkg, oracle, renderer):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full)
     renderer.set_shard(0, 1)
+
+
+def _blob_scene(oracle, n, seed, spread=0.15, sigma=(0.25, 0.45), mag=(0.01, 0.05)):
+    """n wide, faint Gaussians around the view axis: every ray sees all of them (lists as long as the scene)."""
+    rng = np.random.default_rng(seed)
+    mu = rng.normal(size=(n, 3)) * spread + np.array([0, 0, 1.0])
+    return oracle.gaussians(rng.uniform(0.1, 1, size=(n, 4)), mu, rng.uniform(*sigma, n), rng.uniform(*mag, n))
+
+
+@pytest.mark.parametrize("n,w,what", [(300, 16, "per-ray lists > 48: blocks handed to the 16-wave kernel"),
+                                      (1100, 8, "block candidates > 1024: LDS overflow, streamed list"),
+                                      (4200, 4, "cell list > 4096: cell slot overflow, tile list used")])
+def test_capacity_overflow_paths(pkg, oracle, renderer, n, w, what):
+    """Every fixed-capacity structure of the kernels has a correct (slower) way out; heterogeneous sigma/magnitude."""
+    g = _blob_scene(oracle, n, 5 + n)
+    cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, w, tiles_n=1)
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    renderer.enable_stats(True)
+    img, rad = renderer.render(origin)
+    st = renderer.stats()
+    renderer.enable_stats(False)
+    _, orad = oracle.render(w, w, plane, origin, g, tiles, want_image=False)
+    scale = max(1.0, float(orad.max()))
+    assert np.abs(rad.reshape(-1, 4) - orad).max() <= TOL * scale, what
+    assert orad.max() > 0.05
+    if n == 300:
+        assert st["dense_blocks"] > 0
+    else:
+        assert st["overflow_blocks"] > 0
+
+
+def test_erf_saturation_thresholds(pkg, renderer):
+    """The dense kernel skips terms whose Erf is EXACTLY +-1: the thresholds it uses must really saturate."""
+    sat = {pkg.ERF_AS: 5.5, pkg.ERF_LIBM: 4.2, pkg.ERF_SPLINE: 3.1, pkg.ERF_SPLINE_MIRROR: 2.9, pkg.ERF_TAYLOR: 2.0}
+    for kind, s in sat.items():
+        x = np.concatenate([np.linspace(s, s + 3, 4001), np.geomspace(s, 1e6, 2000)]).astype(np.float32)
+        x = x[x >= np.float32(s)]
+        assert (renderer.eval_erf(kind, x) == 1.0).all(), kind
+        assert (renderer.eval_erf(kind, -x) == -1.0).all(), kind
+    # and the A&S threshold is tight: just below it the value is not yet 1
+    assert renderer.eval_erf(pkg.ERF_AS, np.array([5.3], np.float32))[0] < 1.0
