@@ -151,7 +151,6 @@ def main():
         gathered = [torch.zeros(npx * world, dtype=torch.int32, device="cuda") if rank == 0 else None for _ in range(2)]
         glist = [list(gt.chunk(world)) if gt is not None else None for gt in gathered]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     class _Done:
         def wait(self):
@@ -168,23 +167,20 @@ def main():
             gathered[b].copy_(torch.cat(out))
         return _Done()
 
+    frame = r.frame_call(tw, th, view, origin, pack, shard=world > 1)   # tile_gaussians + render, one C call
+    img_ptr = image.data_ptr()
+    shard_ptr = [s_.data_ptr() for s_ in shard] if world > 1 else None
+
     def run(nsteps, timed):
         pending = [None, None]
         for k in range(nsteps):
-            r.tile_gaussians_device(tw, th, view, sp)
-            if timed:
-                ev[k][0].record(stream)
             if world == 1:
-                r.render_device(origin, pack, image.data_ptr(), 0, sp)
-                if timed:
-                    ev[k][1].record(stream)
+                frame(img_ptr, sp)
             else:
                 b = k & 1
                 if pending[b] is not None:
                     pending[b].wait()
-                r.render_shard_device(origin, pack, shard[b].data_ptr(), sp)
-                if timed:
-                    ev[k][1].record(stream)
+                frame(shard_ptr[b], sp)
                 pending[b] = gather_async(b)
                 if k >= 1 and pending[1 - b] is not None:
                     pending[1 - b].wait()
@@ -216,7 +212,6 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     kern_ms = torch.tensor([kt["render_ms"]], dtype=torch.float64, device=red_dev)
-    seq_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)   # lists + both render kernels, per frame
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
@@ -256,7 +251,7 @@ def main():
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                          "launch_sequence_ms": {"lists": kt["lists_ms"], "render_kernel": kt["render_ms"],
-                                                "render_dense_kernel": kt["dense_ms"], "whole_frame_events": seq_ms},
+                                                "render_dense_kernel": kt["dense_ms"]},
                          "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4); see valu"},
             "valu": {"blocks": st["blocks"], "mean_block_list": st["list_entries"] / max(st["blocks"], 1),
                      "mean_tile_list": st["tile_entries"] / max(st["blocks"], 1), "overflow_blocks": st["overflow_blocks"],

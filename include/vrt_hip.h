@@ -116,6 +116,11 @@ int vrt_hip_render(vrt_hip_ctx *ctx, const float origin[3], int pack_flags, uint
 int vrt_hip_render_device(vrt_hip_ctx *ctx, const float origin[3], int pack_flags, uint32_t *d_image,
                           float *d_radiance, void *hip_stream);
 
+/* One animation frame in one call == the body of the reference's frame loop (main.cpp:259-296): tile_gaussians(view)
+ * then render into d_image (raster order) or, when `shard` is non-zero, into this rank's compact shard buffer. */
+int vrt_hip_frame_device(vrt_hip_ctx *ctx, float tw, float th, const float view[16], const float origin[3],
+                         int pack_flags, uint32_t *d_out, int shard, void *hip_stream);
+
 /* Multi-GPU tile sharding: the context renders only tiles t with shard_of(t) == rank.
  * Owned tiles are written tile-major into a compact buffer of
  * vrt_hip_shard_pixels() u32s: [local tile][tile_h][tile_w].  assemble() scatters the

@@ -76,6 +76,14 @@ struct vrt_hip_ctx {
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
     int lists_for_shard = -1; // sharding mode the cell lists were built for
     bool lists_fresh = false; // the queue counters were zeroed by the list build of this very call
+    uint32_t list_gen = 0;    // list generation: selects the counter set (see cell_grid)
+    // dense-launch feedback (CellGrid::feedback): host-mapped, read frames later
+    volatile uint32_t *h_fb = nullptr;
+    uint32_t *d_fb = nullptr;
+    bool fb_valid = false;        // at least one frame of the current scene/options has reported
+    bool dense_launched_last = true;
+    uint32_t fb1_seen = 0;
+    uint64_t frames_since_reset = 0;
     int num_cus = 256;
     int dense_waves = 16; // waves per block in the dense kernel (tuning knob: VRT_HIP_DENSE_WAVES = 4 | 8 | 16)
     bool work_is_ref = false; // render straight from the ref lists (no tile-level cull possible)
@@ -272,7 +280,7 @@ int ensure_device_ref_lists(vrt_hip_ctx *c)
     BinArgs a = bin_args(c);
     a.refine = 0;
     a.out_start = c->w_start.p; a.out_indices = c->ref_indices.p; a.out_count = c->ref_count.p;
-    launch_build_tile_lists(a, false, (uint32_t)nt, c->stream);
+    launch_build_tile_lists(a, FuseArgs{}, false, (uint32_t)nt, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->ref_valid = true;
@@ -282,20 +290,27 @@ int ensure_device_ref_lists(vrt_hip_ctx *c)
 TileLists work_lists(const vrt_hip_ctx *c);
 int rebuild_shard(vrt_hip_ctx *c);
 
+// Queue counters come in two sets used by alternate list generations: a fused list kernel ADDS to its set
+// (cleared one generation earlier by its predecessor) and clears the other set for its successor -- no memset
+// node on the per-frame path.
 CellGrid cell_grid(const vrt_hip_ctx *c)
 {
     CellGrid g{};
+    uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
     g.cells_x = c->cells_x; g.cells_y = c->cells_y; g.cstride = c->cstride;
     g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.inactive = c->c_inactive.p;
     g.dense = c->c_dense.p;
-    g.n_active = c->c_counters.p; g.n_inactive = c->c_counters.p + 1; g.n_dense = c->c_counters.p + 2;
-    g.dense_next = c->c_counters.p + 3;
-    g.overflow = c->c_overflow.p; g.n_overflow = c->c_counters.p + 4;
+    g.n_active = cnt; g.n_inactive = cnt + 1; g.n_dense = cnt + 2;
+    g.dense_next = cnt + 3;
+    g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
+    g.feedback = c->d_fb;
+    g.no_dense = 0;
     return g;
 }
 
-int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool use_shard)
+// `target`: where this frame is rendered to; when the fused list kernel runs it clears the cells nothing can reach.
+int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool use_shard, RenderTarget *target)
 {
     if (!c->lists_dirty && c->lists_for_shard == (int)use_shard) return VRT_HIP_OK;
     int rc = ensure_none_ref_lists(c);
@@ -304,39 +319,8 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     const size_t nt = (size_t)geo.tiles_w * geo.tiles_h;
     // the tile cone is built from corner rays: needs pinhole rays (always true for in-kernel ray generation)
     const bool refine = !c->plane_mode || c->plane_affine;
-    BinArgs a = bin_args(c);
-    a.refine = refine ? 1 : 0;
-    a.R = ray_gen(c, origin);
-    a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
-    c->work_is_ref = false;
-    HIPCHK(c, c->c_counters.reserve(8));
-    a.zero8 = c->c_counters.p;
-    if (c->tile_mode == TILES_DEVICE) {
-        if (c->grid_n != c->n) { // the scene was replaced after tile_gaussians(): re-stride the list buffers
-            HIPCHK(c, hipStreamSynchronize(st));
-            if ((rc = prepare_tile_grid(c, c->tw, c->th))) return rc;
-            a = bin_args(c);
-            a.refine = refine ? 1 : 0; a.R = ray_gen(c, origin);
-            a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
-            a.zero8 = c->c_counters.p;
-        }
-        a.out_start = c->w_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
-        launch_build_tile_lists(a, false, (uint32_t)nt, st);
-    } else if (refine) {
-        const size_t total = c->tile_mode == TILES_NONE ? c->n : c->ref_indices.cap;
-        HIPCHK(c, c->w_count.reserve(nt)); HIPCHK(c, c->w_indices.reserve(total));
-        a.in_start = c->ref_start.p; a.in_count = c->ref_count.p;
-        a.in_indices = c->tile_mode == TILES_NONE ? c->iota.p : c->ref_indices.p;
-        a.tiles_w = geo.tiles_w;
-        a.out_start = c->ref_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
-        launch_build_tile_lists(a, true, (uint32_t)nt, st);
-    } else {
-        c->work_is_ref = true;
-        HIPCHK(c, hipMemsetAsync(c->c_counters.p, 0, 8 * sizeof(uint32_t), st)); // no list kernel ran to clear them
-    }
-    HIPCHK(c, hipGetLastError());
 
-    // second level: cells of the tiles this context renders
+    // geometry of the second level and its buffers
     uint32_t n_local = (uint32_t)nt;
     const uint32_t *tile_map = nullptr;
     if (use_shard) {
@@ -350,7 +334,58 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     HIPCHK(c, c->c_inactive.reserve(c->n_cells)); HIPCHK(c, c->c_dense.reserve(c->n_cells));
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
-    launch_build_cell_lists(tables(c), work_lists(c), cell_grid(c), a.R, tile_map, c->n_cells, refine ? 1 : 0, st);
+    if (!c->c_counters.p) {
+        HIPCHK(c, c->c_counters.reserve(16));
+        HIPCHK(c, hipMemsetAsync(c->c_counters.p, 0, 16 * sizeof(uint32_t), st));
+    }
+    ++c->list_gen; // this build fills counter set (list_gen & 1)
+
+    BinArgs a = bin_args(c);
+    a.refine = refine ? 1 : 0;
+    a.R = ray_gen(c, origin);
+    a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
+    c->work_is_ref = false;
+    if (c->tile_mode == TILES_DEVICE && c->grid_n != c->n) { // the scene was replaced after tile_gaussians()
+        HIPCHK(c, hipStreamSynchronize(st));
+        if ((rc = prepare_tile_grid(c, c->tw, c->th))) return rc;
+        a = bin_args(c);
+        a.refine = refine ? 1 : 0; a.R = ray_gen(c, origin);
+        a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
+    }
+    const bool device_bin = c->tile_mode == TILES_DEVICE;
+    // one fused kernel when a tile's cells fit one workgroup's waves; otherwise tile kernel + one-wave-per-cell kernel
+    const bool fuse = c->cells_x * c->cells_y <= (uint32_t)MAX_FUSED_CELLS && (device_bin || refine);
+    FuseArgs f{};
+    f.enabled = fuse ? 1 : 0;
+    f.tile_map = fuse ? tile_map : nullptr;
+    f.C = cell_grid(c);
+    if (fuse && target) { f.O = *target; f.do_clear = 1; }
+    uint32_t *other_set = c->c_counters.p + 8 * ((c->list_gen + 1) & 1);
+    a.zero8 = fuse ? nullptr : c->c_counters.p + 8 * (c->list_gen & 1);
+    if (device_bin) {
+        a.out_start = c->w_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
+    } else if (refine) {
+        const size_t total = c->tile_mode == TILES_NONE ? c->n : c->ref_indices.cap;
+        HIPCHK(c, c->w_count.reserve(nt)); HIPCHK(c, c->w_indices.reserve(total));
+        a.in_start = c->ref_start.p; a.in_count = c->ref_count.p;
+        a.in_indices = c->tile_mode == TILES_NONE ? c->iota.p : c->ref_indices.p;
+        a.tiles_w = geo.tiles_w;
+        a.out_start = c->ref_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
+    } else {
+        c->work_is_ref = true;
+    }
+    if (fuse) {
+        a.next_zero8 = other_set; // cleared for the next generation by workgroup 0
+        launch_build_tile_lists(a, f, !device_bin, fuse ? n_local : (uint32_t)nt, st);
+        if (target) target->cleared = 1;
+    } else {
+        if (!c->work_is_ref) launch_build_tile_lists(a, f, !device_bin, (uint32_t)nt, st);
+        else HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1), 0, 8 * sizeof(uint32_t), st));
+        HIPCHK(c, hipGetLastError());
+        launch_build_cell_lists(tables(c), work_lists(c), cell_grid(c), a.R, tile_map, c->n_cells, refine ? 1 : 0, st);
+        // the set the NEXT generation will add to (if it is a fused one) must be clear
+        HIPCHK(c, hipMemsetAsync(other_set, 0, 8 * sizeof(uint32_t), st));
+    }
     HIPCHK(c, hipGetLastError());
     c->lists_dirty = false;
     c->lists_fresh = true;
@@ -424,32 +459,48 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         HIPCHK(c, hipEventRecord(tev[0], st));
     }
     if ((rc = prep_frame(c, origin, st))) return rc;
-    if ((rc = build_work_lists(c, origin, st, use_shard))) return rc;
-    const TileLists t = work_lists(c);
-    RenderTarget o;
+    RenderTarget o{};
     o.image = d_image; o.radiance = d_rad; o.pack_flags = pack_flags;
     o.stats = c->stats_on ? c->d_stats.p : nullptr;
+    o.compact = shard_compact ? 1 : 0;
     if (use_shard) {
-        o.tile_map = c->tile_map.p; o.n_local_tiles = c->n_local; o.compact = shard_compact ? 1 : 0;
+        if ((rc = rebuild_shard(c))) return rc;
+        o.tile_map = c->tile_map.p; o.n_local_tiles = c->n_local;
     } else {
-        o.tile_map = nullptr; o.n_local_tiles = t.tiles_w * t.tiles_h; o.compact = 0;
+        o.tile_map = nullptr; o.n_local_tiles = geo.tiles_w * geo.tiles_h;
     }
+    if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
+    const TileLists t = work_lists(c);
     if (o.stats) HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 8 * sizeof(unsigned long long), st));
     const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
     c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
     // persistent grid: 16 wavefronts per CU (LDS- and VGPR-limited residency), never more than there are blocks
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * 16u);
-    if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counter needs a reset
-        HIPCHK(c, hipMemsetAsync(c->c_counters.p + 3, 0, 2 * sizeof(uint32_t), st));
+    if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
+        HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1) + 3, 0, 2 * sizeof(uint32_t), st));
     c->lists_fresh = false;
+    // Is the dense launch worth its ~12 us?  Frames report (asynchronously, see CellGrid::feedback) how many dense
+    // cells / slow-path blocks they had; a few frames after the last change of scene or options the report of
+    // earlier frames predicts this one.  A wrong "no" costs speed only: the one-wave kernel then shades all itself.
+    bool launch_dense = true;
+    if (c->h_fb && c->frames_since_reset >= 8 && !c->stats_on) {
+        const uint32_t fb0 = c->h_fb[0], fb1 = c->h_fb[1], fb2 = c->h_fb[2];
+        launch_dense = fb0 > 0 || (c->dense_launched_last ? fb2 > 0 : fb1 != c->fb1_seen);
+        c->fb1_seen = fb1;
+    }
+    ++c->frames_since_reset;
+    c->dense_launched_last = launch_dense;
+    CellGrid cg = cell_grid(c);
+    cg.no_dense = launch_dense ? 0 : 1;
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
-    launch_render(tables(c), t, cell_grid(c), ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
+    launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
     // dense queue: one 16-wave workgroup per CU pulls blocks until the queue is empty (exits at once if it is)
-    launch_render_dense(tables(c), t, cell_grid(c), ray_gen(c, origin), o,
-                        (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16))),
-                        c->dense_waves, c->exp_kind, c->erf_kind, st);
+    if (launch_dense)
+        launch_render_dense(tables(c), t, cg, ray_gen(c, origin), o,
+                            (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16))),
+                            c->dense_waves, c->exp_kind, c->erf_kind, st);
     if (tev) { HIPCHK(c, hipEventRecord(tev[3], st)); ++c->timing_count; }
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;
@@ -497,6 +548,16 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     c->device = device;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+    {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            memset(hp, 0, 4 * sizeof(uint32_t));
+            c->h_fb = (volatile uint32_t *)hp; c->d_fb = (uint32_t *)dp;
+        } else if (hp) {
+            (void)hipHostFree(hp);
+        }
+    }
     if (const char *e = getenv("VRT_HIP_DENSE_WAVES")) {
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 17) c->dense_waves = v; // 17 = 16 waves without saturation skipping (A/B)
@@ -523,6 +584,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_overflow.release(); c->c_counters.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release();
+    if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
     for (auto &e : c->tev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -549,6 +611,7 @@ int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const flo
     }
     c->has_alpha = aa != nullptr;
     c->n = (uint32_t)n;
+    c->frames_since_reset = 0;
     c->tables_dirty = true;
     c->lists_dirty = true;
     if (c->tile_mode != TILES_HOST) c->ref_valid = false;
@@ -582,6 +645,7 @@ int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_e
                            (exp_kind == VRT_EXP_LIBM && erf_kind == VRT_ERF_LIBM);
     if (!supported) return fail(c, VRT_HIP_ERR_INVALID, "set_options: this Exp/Erf pair is not instantiated");
     if (exp_kind != c->exp_kind || cull_eps != c->cull_eps) c->tables_dirty = true;
+    if (exp_kind != c->exp_kind || erf_kind != c->erf_kind || cull_eps != c->cull_eps) c->frames_since_reset = 0;
     c->exp_kind = exp_kind; c->erf_kind = erf_kind; c->cull_eps = cull_eps;
     return VRT_HIP_OK;
 }
@@ -589,6 +653,7 @@ int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_e
 int vrt_hip_clear_tiles(vrt_hip_ctx *c)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
+    if (c->tile_mode != TILES_NONE) c->frames_since_reset = 0;
     c->tile_mode = TILES_NONE; c->tw = c->th = 2.f; c->tiles_w = c->tiles_h = 1;
     c->shard_dirty = true; c->lists_dirty = true; c->ref_valid = false;
     return VRT_HIP_OK;
@@ -618,6 +683,7 @@ int vrt_hip_set_tiles(vrt_hip_ctx *c, float tw, float th, uint64_t tiles_w, uint
     HIPCHK(c, hipMemcpy(c->ref_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->ref_count.p, count.data(), nt * 4, hipMemcpyHostToDevice));
     if (total) HIPCHK(c, hipMemcpy(c->ref_indices.p, indices, total * 4, hipMemcpyHostToDevice));
+    c->frames_since_reset = 0;
     c->tile_mode = TILES_HOST; c->tw = tw; c->th = th; c->tiles_w = (uint32_t)tiles_w; c->tiles_h = (uint32_t)tiles_h;
     c->shard_dirty = true; c->lists_dirty = true; c->ref_valid = true;
     return VRT_HIP_OK;
@@ -654,7 +720,7 @@ int vrt_hip_tile_gaussians(vrt_hip_ctx *c, float tw, float th, const float view[
     BinArgs a = bin_args(c);
     a.refine = 0;
     a.out_start = c->w_start.p; a.out_indices = c->ref_indices.p; a.out_count = c->ref_count.p;
-    launch_build_tile_lists(a, false, (uint32_t)nt, c->stream);
+    launch_build_tile_lists(a, FuseArgs{}, false, (uint32_t)nt, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -716,6 +782,7 @@ int vrt_hip_set_plane(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float *xs, c
     HIPCHK(c, hipMemcpy(c->ys.p, ys, n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->zs.p, zs, n * 4, hipMemcpyHostToDevice));
     c->plane_affine = plane_is_affine(w, h, xs, ys, zs);
+    if (c->w != w || c->h != h || !c->plane_mode) c->frames_since_reset = 0;
     c->w = w; c->h = h; c->plane_mode = true; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
@@ -726,6 +793,7 @@ int vrt_hip_set_camera(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float pos[3
     if (!c) return VRT_HIP_ERR_INVALID;
     if (!w || !h || !pos || !right || !up || !front) return fail(c, VRT_HIP_ERR_INVALID, "set_camera: bad argument");
     memcpy(c->cam_pos, pos, 12); memcpy(c->cam_right, right, 12); memcpy(c->cam_up, up, 12); memcpy(c->cam_front, front, 12);
+    if (c->w != w || c->h != h || c->plane_mode) c->frames_since_reset = 0;
     c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
@@ -735,6 +803,15 @@ int vrt_hip_render_device(vrt_hip_ctx *c, const float origin[3], int pack_flags,
 {
     if (!c || !origin) return VRT_HIP_ERR_INVALID;
     return render_common(c, origin, pack_flags, d_image, (float4 *)d_radiance, (hipStream_t)hip_stream, false);
+}
+
+int vrt_hip_frame_device(vrt_hip_ctx *c, float tw, float th, const float view[16], const float origin[3], int pack_flags,
+                         uint32_t *d_out, int shard, void *hip_stream)
+{
+    if (!c || !origin || !d_out) return VRT_HIP_ERR_INVALID;
+    int rc = vrt_hip_tile_gaussians_device(c, tw, th, view, hip_stream);
+    if (rc) return rc;
+    return render_common(c, origin, pack_flags, d_out, nullptr, (hipStream_t)hip_stream, shard != 0);
 }
 
 int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *image_out, float *radiance_out)
@@ -748,9 +825,8 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     if (radiance_out) HIPCHK(c, c->d_rad.reserve(npix));
     HIPCHK(c, hipMemsetAsync(c->d_image.p, 0, npix * 4, c->stream));
     if (radiance_out) HIPCHK(c, hipMemsetAsync(c->d_rad.p, 0, npix * 16, c->stream));
-    // tables / frame prep / tile lists outside the timed kernel window
+    // tables / frame prep outside the timed window (list building is part of a frame, like the reference's tiling)
     if ((rc = prep_frame(c, origin, c->stream))) return rc;
-    if ((rc = build_work_lists(c, origin, c->stream, c->world > 1))) return rc;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     rc = render_common(c, origin, pack_flags, c->d_image.p, radiance_out ? c->d_rad.p : nullptr, c->stream, false);
     if (rc) return rc;
@@ -776,7 +852,7 @@ int vrt_hip_set_shard(vrt_hip_ctx *c, int rank, int world)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     if (world < 1 || rank < 0 || rank >= world) return fail(c, VRT_HIP_ERR_INVALID, "set_shard: bad rank/world");
-    c->rank = rank; c->world = world; c->shard_dirty = true; c->lists_dirty = true;
+    c->rank = rank; c->world = world; c->shard_dirty = true; c->lists_dirty = true; c->frames_since_reset = 0;
     return VRT_HIP_OK;
 }
 

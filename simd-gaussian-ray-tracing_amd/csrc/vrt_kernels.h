@@ -9,6 +9,8 @@ namespace vrtk {
 constexpr int BLOCK_W = 8;        // one wavefront = one 8x8 pixel block (64 rays)
 constexpr int BLOCK_H = 8;
 constexpr int CELL = 32;          // second-level cull region: 32x32 pixels = 4x4 blocks
+constexpr int TCAP = 1024;        // a tile's candidates kept in LDS by the fused list kernel
+constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate cell kernel (one wave per cell)
 constexpr int PCAP = 192;         // per-block candidates cached in LDS (index + two parameter rows = 36 B each)
 constexpr int DCAP = 1024;        // per-block candidates the dense kernel keeps in LDS
 constexpr int PL = 48;            // per-lane list capacity (u8 positions into the block's candidates)
@@ -45,6 +47,12 @@ struct CellGrid {
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
                                      // LDS slots: it hands them to the dense kernel, which runs after it
     uint32_t dense_threshold;        // a cell whose list is longer than this goes to the dense queue
+    // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame, [1] = running count of blocks the
+    // one-wave kernel had to shade through its slow path, [2] = items the dense kernel found.  The host reads it
+    // frames later to decide whether the (mostly empty, ~12 us) dense launch can be dropped; `no_dense` tells the
+    // one-wave kernel that no dense kernel follows, so it must shade everything itself.
+    uint32_t *feedback;
+    int no_dense;
 };
 
 struct RayGen {
@@ -64,6 +72,7 @@ struct RenderTarget {
     const uint32_t *tile_map;
     uint32_t n_local_tiles;
     int compact;
+    int cleared;              // inactive cells were already cleared by the list kernel of this frame
     unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
                                // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
 };
@@ -101,8 +110,17 @@ struct BinArgs {
     const uint32_t *out_start;
     uint32_t *out_indices, *out_count;
     uint32_t *zero8;                 // nullable: 8 queue counters this launch clears for the kernels after it
+    uint32_t *next_zero8;            // nullable: the OTHER counter set, cleared for the next list generation
 };
-void launch_build_tile_lists(const BinArgs &a, bool from_list, uint32_t ntiles, hipStream_t st);
+// optional fused second level (see build_tile_lists_kernel)
+struct FuseArgs {
+    int enabled;
+    int do_clear;
+    const uint32_t *tile_map;  // local tile -> tile id (nullptr = identity); the grid is over LOCAL tiles
+    CellGrid C;
+    RenderTarget O;
+};
+void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t n_slots,
                      const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
 void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);

@@ -309,19 +309,67 @@ __device__ __forceinline__ LaneRay pixel_ray(const RayGen &R, uint64_t pix)
 // = dperp cos(theta) - |oc.c| sin(theta); the Gaussian can be dropped for the whole bundle when even that
 // best case gives d^2/(2 sigma^2) > cull_x, i.e. sigma*mag*exp(-..) < cull_eps (or Exp underflows to 0).
 struct Cone { float cx, cy, cz, cos_t, sin_t; };
-__device__ __forceinline__ Cone make_cone(float cx, float cy, float cz, float min_dot)
+// cosine and sine of the angle between unit vectors n and c; the sine from the cross product (1 - cos^2 has
+// no digits left for the milliradian cones of a pixel block)
+__device__ __forceinline__ void cos_sin(float nx, float ny, float nz, float cx, float cy, float cz, float &co, float &si)
+{
+    co = nx * cx + ny * cy + nz * cz;
+    const float ux = ny * cz - nz * cy, uy = nz * cx - nx * cz, uz = nx * cy - ny * cx;
+    si = __builtin_amdgcn_sqrtf(ux * ux + uy * uy + uz * uz);
+}
+__device__ __forceinline__ Cone make_cone(float cx, float cy, float cz, float min_cos, float max_sin)
 {
     Cone k;
     k.cx = cx; k.cy = cy; k.cz = cz;
-    const float c = fminf(min_dot, 1.f);
-    k.sin_t = sqrtf(fmaxf(0.f, 1.f - c * c)) * 1.0001f + 1e-6f; // conservative: never over-estimate
-    k.cos_t = c * 0.9999f;                                       // the distance to the cone
+    k.sin_t = max_sin * 1.001f + 1e-6f;          // conservative: never over-estimate
+    k.cos_t = fminf(min_cos, 1.f) * 0.9999f;     // the distance to the cone
     return k;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// Ray through a pixel for CONE construction only: same geometry as pixel_ray, fast reciprocal square root
+// (shading rays need the reference's exactly rounded normalisation; a cone bound does not).
+__device__ __forceinline__ LaneRay cone_ray(const RayGen &R, uint64_t pix)
+{
+    float px, py, pz;
+    if (R.xs) {
+        px = R.xs[pix]; py = R.ys[pix]; pz = R.zs[pix];
+    } else {
+        const uint32_t jcol = (uint32_t)(pix % R.width), irow = (uint32_t)(pix / R.width);
+        const float x = -1.f + (float)jcol * R.inv_half_w, y = -1.f + (float)irow * R.inv_half_h;
+        px = R.pos[0] + x * R.right[0] + y * R.up[0] - R.focal * R.front[0];
+        py = R.pos[1] + x * R.right[1] + y * R.up[1] - R.focal * R.front[1];
+        pz = R.pos[2] + x * R.right[2] + y * R.up[2] - R.focal * R.front[2];
+    }
+    LaneRay ray;
+    ray.ox = R.origin[0]; ray.oy = R.origin[1]; ray.oz = R.origin[2];
+    const float dx = px - ray.ox, dy = py - ray.oy, dz = pz - ray.oz;
+    const float inv = __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
+    ray.nx = dx * inv; ray.ny = dy * inv; ray.nz = dz * inv;
+    return ray;
+}
+// cone of the pixel rectangle [x0,x1] x [y0,y1] (image coordinates via `at`): axis = centre ray, angle = the
+// farthest corner ray (pinhole rays: the farthest ray of a rectangle on the image plane is a corner ray);
+// lanes 0..3 take a corner each
+template <typename At>
+__device__ __forceinline__ Cone rect_cone(At at, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t lane)
+{
+    const LaneRay c = at((x0 + x1 + 1) / 2, (y0 + y1 + 1) / 2);
+    const LaneRay k = at((lane & 1) ? x1 : x0, (lane & 2) ? y1 : y0);
+    float co, si;
+    cos_sin(k.nx, k.ny, k.nz, c.nx, c.ny, c.nz, co, si);
+    Cone cone = make_cone(c.nx, c.ny, c.nz, wave_min(co), wave_max(si));
+    cone.sin_t += 1e-4f; // the centre pixel is up to half a pixel off the rectangle's centre
+    return cone;
 }
 __device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/, float4 bq /*r,1/2s^2,qK,cull_x*/)
 {
     const float tc = a.x * k.cx + a.y * k.cy + a.z * k.cz;
-    const float dperp = sqrtf(fmaxf(0.f, a.w - tc * tc));
+    const float dperp = __builtin_amdgcn_sqrtf(fmaxf(0.f, a.w - tc * tc));
     const float dmin = fmaxf(0.f, dperp * k.cos_t - fabsf(tc) * k.sin_t);
     const float xmin = dmin * dmin * bq.y;
     return !(xmin * 0.999f - 1e-3f > bq.w);
@@ -357,11 +405,14 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     __shared__ uint8_t s_lane[PL * 64];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x, G = gridDim.x;
     const uint64_t npix = (uint64_t)R.width * R.height;
-    const uint32_t n_inactive = *C.n_inactive, n_active = *C.n_active;
+    const uint32_t n_inactive = *C.n_inactive, n_active = *C.n_active, n_dense_cells = *C.n_dense;
+    if (C.feedback && wave == 0 && lane == 0) C.feedback[0] = n_dense_cells;
+    // without a dense kernel behind it this kernel also walks the dense cells (slow path for what does not fit)
+    const uint32_t n_shade = (n_active + (C.no_dense ? n_dense_cells : 0u)) * 16u;
 
     // ---- clear the cells nothing can reach (4 B per ray: the only HBM traffic of most of the frame) ----
     const uint32_t zero_px = (O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
-    for (uint32_t item = wave; item < n_inactive; item += G) { // one whole cell per item: 16 x (2 rows of 32 px)
+    for (uint32_t item = wave; item < n_inactive && !O.cleared; item += G) { // one whole cell per item: 16 x (2 rows of 32 px)
         const uint32_t cell = C.inactive[item];
         const uint32_t cpt = C.cells_x * C.cells_y;
         const uint32_t lt = cell / cpt, ci = cell % cpt;
@@ -381,8 +432,9 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     }
 
     // ---- shade ----
-    for (uint32_t item = wave; item < n_active * 16u; item += G) {
-        const uint32_t cell = C.active[item >> 4];
+    for (uint32_t item = wave; item < n_shade; item += G) {
+        const uint32_t ci = item >> 4;
+        const uint32_t cell = ci < n_active ? C.active[ci] : C.dense[ci - n_active];
         const BlockPos p = block_of(T, C, O, cell, item & 15u, lane);
         if (!p.inside) continue;
         const uint32_t tx = p.t % T.tiles_w, ty = p.t / T.tiles_w;
@@ -404,10 +456,12 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
         float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
         float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
         {
-            const float inv = 1.f / sqrtf(cx * cx + cy * cy + cz * cz);
+            const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy + cz * cz);
             cx *= inv; cy *= inv; cz *= inv;
         }
-        const Cone cone = make_cone(cx, cy, cz, wave_min(ray.nx * cx + ray.ny * cy + ray.nz * cz));
+        float co, si;
+        cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
+        const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
 
         // ---- block cull over the cell's list (ballot compaction, order preserving) ----
         __syncthreads(); // previous item's LDS reads are done
@@ -445,8 +499,19 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
             fast = __ballot(nl > PL) == 0ull;
         }
         __syncthreads();
-        if (!fast) { // hand the block to the 16-waves-per-block kernel that runs after this one
+        if (!fast && !C.no_dense) { // hand the block to the 16-waves-per-block kernel that runs after this one
             if (lane == 0) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | (item & 15u);
+            continue;
+        }
+        if (!fast) { // nobody to hand it to: stream the list through scalar loads (any length, one wave)
+            if (C.feedback && lane == 0) __hip_atomic_fetch_add(&C.feedback[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (O.stats && lane == 0) { atomicAdd(&O.stats[2], 1ull); atomicAdd(&O.stats[5], 1ull); }
+            float Lr, Lg, Lb, La;
+            shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La);
+            if (valid) {
+                if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
+                if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
+            }
             continue;
         }
         if (O.stats && lane == 0) {
@@ -495,6 +560,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
     constexpr float SAT = erf_saturation<ERF>();
     constexpr float SAT_M = SAT + 1e-3f; // the range bounds are re-associated forms of the arguments: keep a margin
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
+    if (C.feedback && blockIdx.x == 0 && tid == 0) C.feedback[2] = n_items;
 
     for (;;) {
         __syncthreads(); // everyone is done with the previous item's LDS
@@ -523,10 +589,12 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
         float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
         float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
         {
-            const float inv = 1.f / sqrtf(cx * cx + cy * cy + cz * cz);
+            const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy + cz * cz);
             cx *= inv; cy *= inv; cz *= inv;
         }
-        const Cone cone = make_cone(cx, cy, cz, wave_min(ray.nx * cx + ray.ny * cy + ray.nz * cz));
+        float co, si;
+        cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
+        const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
 
         // ---- cooperative block cull, order preserving across the 16 waves ----
         uint32_t cnt = 0;
@@ -790,34 +858,37 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st)
 // The reference-set arithmetic is kept unfused and in the reference's order so that inclusion
 // decisions (a "<=" on floats) reproduce the host algorithm; order of indices is preserved.
 // ---------------------------------------------------------------------------------------------
+// With F.enabled the same workgroup goes on to the second level: the tile's surviving candidates stay in LDS
+// (index + the two parameter rows the cone test reads) and each of its 16 waves filters them for the tile's
+// 32x32-pixel cells, files every cell as inactive / active / dense (three atomics per TILE) and clears the
+// pixels of inactive cells on the spot -- no second kernel, no global round trip, no idle clear phase later.
 template <bool FROM_LIST>
-__global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P)
+__global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseArgs F)
 {
     __shared__ uint32_t s_wave_cnt[16];
-    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t s_idx[TCAP];
+    __shared__ float4 s_A[TCAP], s_B[TCAP];
+    __shared__ uint32_t s_flag[MAX_FUSED_CELLS];
+    __shared__ uint32_t s_base[3];
+    const uint32_t lt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t t = F.tile_map ? F.tile_map[lt] : lt;
     const uint32_t tx = t % P.tiles_w, ty = t / P.tiles_w;
-    if (P.zero8 && t == 0 && tid < 8) P.zero8[tid] = 0; // saves a 5 us memset node per frame
+    // the queue counters are cleared by the PREVIOUS frame's last kernel or a memset when fusing (this kernel
+    // adds to them); the unfused pipeline clears them here for the cell kernel that follows
+    if (P.zero8 && !F.enabled && lt == 0 && tid < 8) P.zero8[tid] = 0;
+    if (P.next_zero8 && lt == 0 && tid < 8) P.next_zero8[tid] = 0;
 
     // (b) tile cone from the centre and the four corner pixels of the tile (pinhole rays: the
     // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
     Cone cone = {};
     if (P.refine) {
-        const uint64_t npix = (uint64_t)P.R.width * P.R.height;
-        const uint32_t x0 = tx * P.tile_w, y0 = ty * P.tile_h, x1 = x0 + P.tile_w - 1, y1 = y0 + P.tile_h - 1;
+        const uint64_t npix0 = (uint64_t)P.R.width * P.R.height;
         auto at = [&](uint32_t x, uint32_t y) {
-            uint64_t pix = (uint64_t)x + (uint64_t)P.stride * y;
-            if (pix >= npix) pix = npix - 1;
-            return pixel_ray(P.R, pix);
+            uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
+            if (pix >= npix0) pix = npix0 - 1;
+            return cone_ray(P.R, pix);
         };
-        const LaneRay c = at(x0 + P.tile_w / 2, y0 + P.tile_h / 2);
-        float md = 1.f;
-        const LaneRay k0 = at(x0, y0), k1 = at(x1, y0), k2 = at(x0, y1), k3 = at(x1, y1);
-        md = fminf(md, k0.nx * c.nx + k0.ny * c.ny + k0.nz * c.nz);
-        md = fminf(md, k1.nx * c.nx + k1.ny * c.ny + k1.nz * c.nz);
-        md = fminf(md, k2.nx * c.nx + k2.ny * c.ny + k2.nz * c.nz);
-        md = fminf(md, k3.nx * c.nx + k3.ny * c.ny + k3.nz * c.nz);
-        cone = make_cone(c.nx, c.ny, c.nz, md);
-        cone.sin_t += 1e-4f; // the centre pixel is up to half a pixel off the rectangle's centre
+        cone = rect_cone(at, 0, 0, P.tile_w - 1, P.tile_h - 1, lane);
     }
 
     float x = 0.f, y = 0.f, ax = 0.f, ay = 0.f;
@@ -838,28 +909,35 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P)
         const uint32_t k = base + tid;
         bool keep = false;
         uint32_t idx = 0;
+        float4 ga, gb;
         if (k < n_in) {
-            if constexpr (FROM_LIST) {
-                idx = in_list[k];
-                keep = true;
-            } else {
+            idx = FROM_LIST ? in_list[k] : k;
+            keep = true;
+            // The result is (reference tile test) AND (cone test).  The cone test goes first: it is the cheaper
+            // one (no divisions) and drops >95 % of the pairs in sparse scenes.
+            if (P.refine || F.enabled) {
+                ga = P.gA[idx]; gb = P.gB[idx];
+                if (P.refine) keep = cone_keeps(cone, ga, gb);
+            }
+            if constexpr (!FROM_LIST) {
+                if (keep) {
 #pragma clang fp contract(off)
-                idx = k;
-                const float4 g = P.mu_sig[idx];
-                // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
-                const float vx = (P.V.m[0] * g.x + P.V.m[4] * g.y) + (P.V.m[8] * g.z + P.V.m[12] * 1.f);
-                const float vy = (P.V.m[1] * g.x + P.V.m[5] * g.y) + (P.V.m[9] * g.z + P.V.m[13] * 1.f);
-                const float vz = (P.V.m[2] * g.x + P.V.m[6] * g.y) + (P.V.m[10] * g.z + P.V.m[14] * 1.f);
-                if (!(vz < 1.f)) {                       // rt.cpp:38
-                    const float sig = g.w / vz;          // rt.cpp:40
-                    if (!(sig < 1e-5f)) {                // rt.cpp:41
-                        const float dx = fabsf(x - vx / vz), dy = fabsf(y - vy / vz);
-                        const float s33 = 3.3f * sig;
-                        keep = (dx <= ax + s33) && (dy <= ay + s33); // rt.cpp:58-59
+                    keep = false;
+                    const float4 g = P.mu_sig[idx];
+                    // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
+                    const float vx = (P.V.m[0] * g.x + P.V.m[4] * g.y) + (P.V.m[8] * g.z + P.V.m[12] * 1.f);
+                    const float vy = (P.V.m[1] * g.x + P.V.m[5] * g.y) + (P.V.m[9] * g.z + P.V.m[13] * 1.f);
+                    const float vz = (P.V.m[2] * g.x + P.V.m[6] * g.y) + (P.V.m[10] * g.z + P.V.m[14] * 1.f);
+                    if (!(vz < 1.f)) {                       // rt.cpp:38
+                        const float sig = g.w / vz;          // rt.cpp:40
+                        if (!(sig < 1e-5f)) {                // rt.cpp:41
+                            const float dx = fabsf(x - vx / vz), dy = fabsf(y - vy / vz);
+                            const float s33 = 3.3f * sig;
+                            keep = (dx <= ax + s33) && (dy <= ay + s33); // rt.cpp:58-59
+                        }
                     }
                 }
             }
-            if (keep && P.refine) keep = cone_keeps(cone, P.gA[idx], P.gB[idx]);
         }
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
@@ -871,18 +949,93 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P)
             before += (wv < wave) ? c : 0;
             chunk += c;
         }
-        if (keep) out[total + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0))] = idx;
+        if (keep) {
+            const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            out[pos] = idx;
+            if (F.enabled && pos < TCAP) { s_idx[pos] = idx; s_A[pos] = ga; s_B[pos] = gb; }
+        }
         total += chunk;
         __syncthreads();
     }
     if (tid == 0) P.out_count[t] = total;
+    if (!F.enabled) return;
+
+    // ---------------- second level, fused ----------------
+    const CellGrid &C = F.C;
+    const uint32_t cpt = C.cells_x * C.cells_y;
+    const uint64_t npix = (uint64_t)P.R.width * P.R.height;
+    for (uint32_t ci = wave; ci < cpt; ci += 16) {
+        const uint32_t cell = lt * cpt + ci;
+        const uint32_t x0 = (ci % C.cells_x) * CELL, y0 = (ci / C.cells_x) * CELL;
+        const uint32_t x1 = min(x0 + CELL, P.tile_w) - 1, y1 = min(y0 + CELL, P.tile_h) - 1;
+        uint32_t ctotal = 0;
+        if (total > TCAP) {
+            ctotal = 0xFFFFFFFFu; // the tile's list did not fit LDS: its cells use the tile list itself
+        } else if (total) {
+            Cone cc = {};
+            if (P.refine) {
+                auto at = [&](uint32_t x, uint32_t y) {
+                    uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
+                    if (pix >= npix) pix = npix - 1;
+                    return cone_ray(P.R, pix);
+                };
+                cc = rect_cone(at, x0, y0, x1, y1, lane);
+            }
+            uint32_t *cout = C.indices + (size_t)cell * C.cstride;
+            for (uint32_t base = 0; base < total; base += 64) {
+                const uint32_t k = base + lane;
+                const bool keep = k < total && (!P.refine || cone_keeps(cc, s_A[k], s_B[k]));
+                const unsigned long long mask = __ballot(keep);
+                const uint32_t pos = ctotal + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                if (keep && pos < C.cstride) cout[pos] = s_idx[k];
+                ctotal += (uint32_t)__popcll(mask);
+            }
+            if (ctotal > C.cstride) ctotal = 0xFFFFFFFFu;
+        }
+        if (lane == 0) {
+            C.count[cell] = ctotal;
+            s_flag[ci] = ctotal ? (ctotal > C.dense_threshold ? 3u : 1u) : 0u;
+        }
+        if (ctotal == 0 && F.do_clear) { // nothing reaches this cell: clear its pixels now
+            const uint32_t zero_px = (F.O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
+            const uint32_t pxt = x0 + (lane & 31);
+#pragma unroll 4
+            for (uint32_t pass = 0; pass < CELL / 2; ++pass) {
+                const uint32_t pyt = y0 + pass * 2 + (lane >> 5);
+                const uint64_t pix = (uint64_t)(tx * P.tile_w + pxt) + (uint64_t)P.stride * (ty * P.tile_h + pyt);
+                if (pxt < P.tile_w && pyt < P.tile_h && pix < npix) {
+                    const uint64_t o = F.O.compact ? ((uint64_t)lt * P.tile_h + pyt) * P.tile_w + pxt : pix;
+                    if (F.O.image) F.O.image[o] = zero_px;
+                    if (F.O.radiance) F.O.radiance[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t na = 0, ni = 0, nd = 0;
+        for (uint32_t k = 0; k < cpt; ++k) { na += s_flag[k] == 1u; ni += s_flag[k] == 0u; nd += s_flag[k] == 3u; }
+        s_base[0] = na ? atomicAdd(C.n_active, na) : 0u;
+        s_base[1] = ni ? atomicAdd(C.n_inactive, ni) : 0u;
+        s_base[2] = nd ? atomicAdd(C.n_dense, nd) : 0u;
+    }
+    __syncthreads();
+    if (tid < cpt) {
+        uint32_t before = 0;
+        const uint32_t mine = s_flag[tid];
+        for (uint32_t k = 0; k < tid; ++k) before += s_flag[k] == mine;
+        const uint32_t cell = lt * cpt + tid;
+        if (mine == 1u) C.active[s_base[0] + before] = cell;
+        else if (mine == 3u) C.dense[s_base[2] + before] = cell;
+        else C.inactive[s_base[1] + before] = cell;
+    }
 }
 
-void launch_build_tile_lists(const BinArgs &a, bool from_list, uint32_t ntiles, hipStream_t st)
+void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st)
 {
     if (!ntiles) return;
-    if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, a);
+    if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, a, f);
+    else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, a, f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -914,13 +1067,9 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
                 auto at = [&](uint32_t x, uint32_t y) {
                     uint64_t pix = (uint64_t)(tx * T.tile_w + x) + (uint64_t)T.stride * (ty * T.tile_h + y);
                     if (pix >= npix) pix = npix - 1;
-                    return pixel_ray(R, pix);
+                    return cone_ray(R, pix);
                 };
-                // lanes 0..3 take a corner each, everyone the centre
-                const LaneRay c = at((x0 + x1 + 1) / 2, (y0 + y1 + 1) / 2);
-                const LaneRay k = at((lane & 1) ? x1 : x0, (lane & 2) ? y1 : y0);
-                cone = make_cone(c.nx, c.ny, c.nz, wave_min(k.nx * c.nx + k.ny * c.ny + k.nz * c.nz));
-                cone.sin_t += 1e-4f; // the centre pixel is up to half a pixel off the rectangle's centre
+                cone = rect_cone(at, x0, y0, x1, y1, lane);
             }
             const uint32_t *in_list = T.indices + T.start[t];
             uint32_t *out = C.indices + (size_t)cell * C.cstride;
