@@ -36,7 +36,8 @@ def load_pkg():
 
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TOPS = 78.6        # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-instructions/s (157.3 TFLOP/s / 2)
+VALU_PEAK_WAVE_INSTR = 1024 / 1.24e-9   # measured on MI355X (scratch/ubench/valu.hip): one v_fma_f32 wave-instruction
+                                        # per 1.24 ns per SIMD with >= 2 waves/SIMD, 1024 SIMDs (= 5.3e13 lane-ops/s)
 
 
 def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
@@ -221,15 +222,9 @@ def main():
     if rank == 0:
         rays = w * h * args.steps
         ms_per_step = elapsed / args.steps * 1e3
-        # ---- render-kernel roofline (DESIGN.md "Measurement") ----
-        # algorithmic HBM bytes per launch: 4 B/ray framebuffer write (+12 B/ray plane read in
-        # --plane-arrays mode) + the scene tables once (64 B/Gaussian) + the tile index lists once (4 B/entry)
+        # ---- statistics pass (outside the timed region): list lengths, shaded blocks ----
         counts = r.tile_counts()
         n_entries = int(counts.sum())
-        rays_launch = (w * h) // world if world > 1 else w * h
-        alg_bytes = rays_launch * (4 + (12 if args.plane_arrays else 0)) + 64 * len(g) + 4 * n_entries // world
-        achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        # VALU accounting from a stats pass (outside the timed region)
         r.enable_stats(True)
         r.set_shard(0, 1)
         _img, _ = r.render(origin, pack, want_radiance=False)
@@ -238,6 +233,30 @@ def main():
         st = r.stats()
         r.enable_stats(False)
         r.set_shard(rank, world)
+        sb = max(st["shaded_blocks"], 1)
+        # ---- roofline.  Algorithmic HBM bytes: 4 B per ray written (+12 B per ray
+        # read with --plane-arrays), the Gaussian rows once (64 B each), the candidate lists once (4 B per entry).
+        # Dominant kernel = render_kernel: it writes the rays it shades and reads their cells' lists; the other rays
+        # of the frame are cleared by the list kernel, so the FRAME figure is given next to it.
+        per_ray = 4 + (12 if args.plane_arrays else 0)
+        render_bytes = (sb * 64 * per_ray + 4 * st["tile_entries"] + 64 * len(g)) / world
+        frame_bytes = (w * h * per_ray + 64 * len(g) + 4 * n_entries) / world
+        render_gbs = render_bytes / (kernel_ms * 1e-3) / 1e9
+        frame_ms = kt["lists_ms"] + kt["render_ms"] + kt["dense_ms"]
+        frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
+        traffic, traffic_frame, valu = None, None, None
+        try:    # PMC passes are separate runs (profiles/README.md); their committed summary supplies `traffic`
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
+            if world == 1 and args.grid == 64 and w == 2048 and not args.plane_arrays:
+                traffic = pmc["render_kernel_traffic_bytes_per_launch"]["lower"]
+                traffic_frame = pmc["frame_hbm_bytes"]["write"] + pmc["frame_hbm_bytes"]["fetch_raw"]
+                nv = pmc.get("sq_counters_bench_scene_per_launch", {}).get("render_kernel", {}).get("SQ_INSTS_VALU")
+                if nv:
+                    rate = nv / (kernel_ms * 1e-3)
+                    valu = {"wave_instructions_per_launch": nv, "achieved_per_s": rate, "peak_per_s": VALU_PEAK_WAVE_INSTR,
+                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01b_pmc_traffic.json (SQ_INSTS_VALU)"}
+        except (OSError, KeyError, ValueError):
+            pass
         result = {
             "metric": "Mrays/sec (whole node), 2048^2 image, 64x64 Gaussian grid", "value": rays / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -247,16 +266,19 @@ def main():
                        "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
                        "parallelism": f"tile-shard x{world}" + (" + RCCL gather" if world > 1 else ""),
                        "frame_equals_single_gpu_frame": frame_ok},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+            "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": render_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": render_bytes,
                          "launch_sequence_ms": {"lists": kt["lists_ms"], "render_kernel": kt["render_ms"],
                                                 "render_dense_kernel": kt["dense_ms"]},
-                         "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4); see valu"},
-            "valu": {"blocks": st["blocks"], "mean_block_list": st["list_entries"] / max(st["blocks"], 1),
-                     "mean_tile_list": st["tile_entries"] / max(st["blocks"], 1), "overflow_blocks": st["overflow_blocks"],
-                     "mean_ray_list": st["lane_entries"] / max(st["rays"], 1),
-                     "mean_block_longest_ray_list": st["lane_max_entries"] / max(st["blocks"], 1)},
+                         "frame": {"algorithmic_bytes": frame_bytes, "ms": frame_ms, "achieved": frame_gbs,
+                                   "frac": frame_gbs / HBM_PEAK_GBS, "traffic": traffic_frame},
+                         "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4): see valu; "
+                                 "traffic = WRITE_SIZE + raw FETCH_SIZE of separate PMC passes (profiles/)"},
+            "valu": {"issue": valu, "blocks": st["blocks"], "shaded_blocks": st["shaded_blocks"], "dense_blocks": st["dense_blocks"],
+                     "mean_cell_list": st["tile_entries"] / sb, "mean_block_list": st["list_entries"] / sb,
+                     "mean_ray_list": st["lane_entries"] / (sb * 64), "mean_block_longest_ray_list": st["lane_max_entries"] / sb,
+                     "slow_path_blocks": st["overflow_blocks"]},
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(scene, g, w, h, args.tiles, args.grid, "")

@@ -107,6 +107,16 @@ __device__ __forceinline__ void ray_gaussian(const SceneTables &S, uint32_t idx,
     }
 }
 
+// One emission sample: pdf * T * sigma = q Exp(-x_pdf) Exp(acc).  For the accurate Exp variants the two
+// exponentials are merged into one (Exp(a)Exp(b) = Exp(a+b) to ~1e-7 relative); the approximating variants
+// (fast_exp, spline_exp) are not multiplicative and keep the reference's two calls.
+template <int EXP>
+__device__ __forceinline__ float emission_term(float q, float x_pdf, float acc)
+{
+    if constexpr (EXP == VRT_EXP_VCL || EXP == VRT_EXP_LIBM) return q * vexp<EXP>(acc - x_pdf);
+    else return q * vexp<EXP>(-x_pdf) * vexp<EXP>(acc);
+}
+
 // list: wave-uniform index list (LDS or global, read through a flat pointer); n entries.
 template <int EXP, int ERF, int EC, bool UNIFORM_ORIGIN>
 __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t *list, uint32_t n, const LaneRay &ray,
@@ -175,8 +185,7 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
                     const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
                     const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
                     const float dd = dot3_ref(px, py, pz, px, py, pz);
-                    const float T = vexp<EXP>(acc[e][k]);
-                    inner = __builtin_fmaf(q * vexp<EXP>(-(dd * bq.y)), T, inner);
+                    inner += emission_term<EXP>(q, dd * bq.y, acc[e][k]);
                 }
                 const float4 alb = uload(S.gC, e_idx[e]);
                 Lr = __builtin_fmaf(alb.x, inner, Lr);
@@ -262,8 +271,7 @@ __device__ __forceinline__ void shade_lanes(const SceneTables &S, const uint32_t
                     const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
                     const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
                     const float dd = dot3_ref(px, py, pz, px, py, pz);
-                    const float T = vexp<EXP>(acc[e][k]);
-                    inner = __builtin_fmaf(q * vexp<EXP>(-(dd * inv2s2)), T, inner);
+                    inner += emission_term<EXP>(q, dd * inv2s2, acc[e][k]);
                 }
                 const float4 alb = S.gC[idx];
                 Lr = __builtin_fmaf(alb.x, inner, Lr);
@@ -719,8 +727,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                             const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
                             const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
                             const float dd = dot3_ref(px, py, pz, px, py, pz);
-                            const float Tk = vexp<EXP>(acc[e][k] + common);
-                            inner = __builtin_fmaf(q * vexp<EXP>(-(dd * inv2s2)), Tk, inner);
+                            inner += emission_term<EXP>(q, dd * inv2s2, acc[e][k] + common);
                         }
                         const float4 alb = uload(S.gC, e_idx[e]);
                         Lr = __builtin_fmaf(alb.x, inner, Lr);
@@ -868,8 +875,8 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
     __shared__ uint32_t s_wave_cnt[16];
     __shared__ uint32_t s_idx[TCAP];
     __shared__ float4 s_A[TCAP], s_B[TCAP];
-    __shared__ uint32_t s_flag[MAX_FUSED_CELLS];
-    __shared__ uint32_t s_base[3];
+    __shared__ uint32_t s_flag[MAX_FUSED_CELLS], s_inact[MAX_FUSED_CELLS];
+    __shared__ uint32_t s_base[4];
     const uint32_t lt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t t = F.tile_map ? F.tile_map[lt] : lt;
     const uint32_t tx = t % P.tiles_w, ty = t / P.tiles_w;
@@ -996,25 +1003,15 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
             C.count[cell] = ctotal;
             s_flag[ci] = ctotal ? (ctotal > C.dense_threshold ? 3u : 1u) : 0u;
         }
-        if (ctotal == 0 && F.do_clear) { // nothing reaches this cell: clear its pixels now
-            const uint32_t zero_px = (F.O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
-            const uint32_t pxt = x0 + (lane & 31);
-#pragma unroll 4
-            for (uint32_t pass = 0; pass < CELL / 2; ++pass) {
-                const uint32_t pyt = y0 + pass * 2 + (lane >> 5);
-                const uint64_t pix = (uint64_t)(tx * P.tile_w + pxt) + (uint64_t)P.stride * (ty * P.tile_h + pyt);
-                if (pxt < P.tile_w && pyt < P.tile_h && pix < npix) {
-                    const uint64_t o = F.O.compact ? ((uint64_t)lt * P.tile_h + pyt) * P.tile_w + pxt : pix;
-                    if (F.O.image) F.O.image[o] = zero_px;
-                    if (F.O.radiance) F.O.radiance[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t na = 0, ni = 0, nd = 0;
-        for (uint32_t k = 0; k < cpt; ++k) { na += s_flag[k] == 1u; ni += s_flag[k] == 0u; nd += s_flag[k] == 3u; }
+        for (uint32_t k = 0; k < cpt; ++k) {
+            na += s_flag[k] == 1u; nd += s_flag[k] == 3u;
+            if (s_flag[k] == 0u) s_inact[ni++] = k;
+        }
+        s_base[3] = ni;
         s_base[0] = na ? atomicAdd(C.n_active, na) : 0u;
         s_base[1] = ni ? atomicAdd(C.n_inactive, ni) : 0u;
         s_base[2] = nd ? atomicAdd(C.n_dense, nd) : 0u;
@@ -1028,6 +1025,36 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
         if (mine == 1u) C.active[s_base[0] + before] = cell;
         else if (mine == 3u) C.dense[s_base[2] + before] = cell;
         else C.inactive[s_base[1] + before] = cell;
+    }
+
+    // ---- clear the cells nothing can reach: 4 B per ray, most of the frame's HBM traffic.  All 1024 threads,
+    //      16-byte stores (4 pixels per lane, 512 B per row segment) when the geometry is 4-pixel aligned ----
+    if (!F.do_clear) return;
+    const uint32_t zero_px = (F.O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
+    const bool wide = F.O.image && !F.O.radiance && (P.tile_w % 4 == 0) && (P.stride % 4 == 0) &&
+                      ((uintptr_t)F.O.image % 16 == 0) && (!F.O.compact || (P.tile_w * P.tile_h) % 4 == 0);
+    const uint32_t n_inact = s_base[3];
+    if (wide) {
+        for (uint32_t it = tid; it < n_inact * (CELL * CELL / 4); it += 1024) { // one 4-pixel quad per item
+            const uint32_t ci = s_inact[it / (CELL * CELL / 4)], q = it % (CELL * CELL / 4);
+            const uint32_t pxt = (ci % C.cells_x) * CELL + (q % (CELL / 4)) * 4, pyt = (ci / C.cells_x) * CELL + q / (CELL / 4);
+            const uint64_t pix = (uint64_t)(tx * P.tile_w + pxt) + (uint64_t)P.stride * (ty * P.tile_h + pyt);
+            if (pxt < P.tile_w && pyt < P.tile_h && pix + 3 < npix) {
+                const uint64_t o = F.O.compact ? ((uint64_t)lt * P.tile_h + pyt) * P.tile_w + pxt : pix;
+                *reinterpret_cast<uint4 *>(F.O.image + o) = make_uint4(zero_px, zero_px, zero_px, zero_px);
+            }
+        }
+    } else {
+        for (uint32_t it = tid; it < n_inact * (CELL * CELL); it += 1024) {
+            const uint32_t ci = s_inact[it / (CELL * CELL)], q = it % (CELL * CELL);
+            const uint32_t pxt = (ci % C.cells_x) * CELL + q % CELL, pyt = (ci / C.cells_x) * CELL + q / CELL;
+            const uint64_t pix = (uint64_t)(tx * P.tile_w + pxt) + (uint64_t)P.stride * (ty * P.tile_h + pyt);
+            if (pxt < P.tile_w && pyt < P.tile_h && pix < npix) {
+                const uint64_t o = F.O.compact ? ((uint64_t)lt * P.tile_h + pyt) * P.tile_w + pxt : pix;
+                if (F.O.image) F.O.image[o] = zero_px;
+                if (F.O.radiance) F.O.radiance[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
     }
 }
 
