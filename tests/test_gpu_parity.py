@@ -325,3 +325,88 @@ def test_erf_saturation_thresholds(pkg, renderer):
         assert (renderer.eval_erf(kind, -x) == -1.0).all(), kind
     # and the A&S threshold is tight: just below it the value is not yet 1
     assert renderer.eval_erf(pkg.ERF_AS, np.array([5.3], np.float32))[0] < 1.0
+
+
+@pytest.mark.parametrize("w,h,tiles_n", [(100, 100, 5), (96, 64, 3), (100, 100, 16), (72, 40, 2)])
+def test_ragged_geometry(pkg, oracle, renderer, w, h, tiles_n):
+    """Tile sizes that are not multiples of 8 or 32, non-square images, and the reference's truncated tile size
+    (rt.h:348-349) with its row stride tile_w*tiles_w != width (rt.h:364-365): same pixels, same values."""
+    g = oracle.grid_scene(6)
+    cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h, tiles_n=tiles_n)
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    img, rad = renderer.render(origin)
+    tile_w, tile_h = int(np.float32(w) * tiles["tw"] / np.float32(2)), int(np.float32(h) * tiles["th"] / np.float32(2))
+    stride = tile_w * tiles["w"]
+    n_written = stride * tile_h * tiles["h"]
+    pix = np.arange(min(n_written, w * h), dtype=np.uint32)
+    oimg, orad = oracle.render(w, h, plane, origin, g, tiles, pixels=pix)
+    assert np.abs(rad.reshape(-1, 4)[pix] - orad).max() <= TOL
+    assert np.abs(channels(img.reshape(-1)[pix]) - channels(oimg[pix])).max() <= 1
+    assert orad.max() > 0.01
+    # pixels the reference never writes stay cleared here
+    assert (img.reshape(-1)[len(pix):] == 0).all()
+
+
+def test_error_reporting(pkg, oracle, renderer):
+    """Status codes + messages instead of the reference's _exit(1) (definitions.h:23-30)."""
+    import ctypes as C
+    L = pkg.lib()
+    g = oracle.grid_scene(2)
+    renderer.set_gaussians(g)
+    h = renderer._h
+    off = (C.c_uint32 * 2)(0, 1)
+    bad = (C.c_uint32 * 1)(99)
+    assert L.vrt_hip_set_tiles(h, 2.0, 2.0, 1, 1, off, bad) == -1
+    assert b"out of range" in L.vrt_hip_last_error(h)
+    assert L.vrt_hip_set_tiles(h, -1.0, 2.0, 1, 1, off, bad) == -1
+    assert L.vrt_hip_set_options(h, 9, 1, C.c_float(0.0)) == -1
+    assert L.vrt_hip_set_options(h, pkg.EXP_FAST, pkg.ERF_TAYLOR, C.c_float(0.0)) == -1   # pair not instantiated
+    assert L.vrt_hip_set_shard(h, 3, 2) == -1
+    fresh = pkg.Renderer(0)
+    try:
+        with pytest.raises(pkg.VrtHipError, match="set_plane/set_camera"):
+            fresh.render((0, 0, -4))
+        fresh.set_gaussians(g[:0])
+        cam, _ = oracle.cli_camera(16, 16)
+        fresh.set_plane(16, 16, *oracle.camera_plane(cam))
+        img, rad = fresh.render((0, 0, -4))            # empty scene renders an empty image
+        assert (img == 0).all()
+    finally:
+        fresh.close()
+    renderer.clear_tiles()
+
+
+def test_animation_loop_matches_fresh_contexts(pkg, oracle, renderer):
+    """The CLI's orbit loop (main.cpp:257-334): re-tiling and re-rendering from a moving camera through ONE context
+    (cached tables, double-buffered queues, launch feedback) must equal an independent render of every pose,
+    including when the dense kernel gets dropped and picked up again."""
+    import torch
+    from sgrt_amd import scene
+    w = h = 128
+    g = oracle.read_obj(os.path.join(GOLDEN, "test-objects", "cube.obj"))
+    renderer.set_gaussians(g)
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    cam, angle = scene.cli_camera(w, h)
+    out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    frames = []
+    for k in range(14):
+        renderer.set_camera(w, h, cam.position, cam.right, cam.up, cam.front, 1.0)
+        renderer.frame_call(2 / 16, 2 / 16, cam.view, cam.position, pack)(out.data_ptr(), st)
+        torch.cuda.synchronize()
+        frames.append((out.cpu().numpy().view(np.uint32).copy(), cam.position.copy(), cam.right.copy(), cam.up.copy(),
+                       cam.front.copy(), cam.view.copy()))
+        cam.orbit(25.0); angle = np.float32(angle - np.float32(25.0)); cam.turn(angle, 0.0)
+    fresh = pkg.Renderer(0)
+    try:
+        fresh.set_gaussians(g)
+        for k in (0, 5, 9, 13):
+            img, pos, right, up, front, view = frames[k]
+            fresh.set_camera(w, h, pos, right, up, front, 1.0)
+            fresh.tile_gaussians(2 / 16, 2 / 16, view)
+            ref, _ = fresh.render(pos, want_radiance=False)
+            np.testing.assert_array_equal(img, ref.reshape(-1))
+            assert (img >> 24).max() > 100
+    finally:
+        fresh.close()
