@@ -118,14 +118,16 @@ __device__ __forceinline__ float emission_term(float q, float x_pdf, float acc)
 }
 
 // list: wave-uniform index list (LDS or global, read through a flat pointer); n entries.
+// Emitter chunks i_start, i_start + i_step, ... (default: all of them) -- a workgroup can deal them to its waves.
 template <int EXP, int ERF, int EC, bool UNIFORM_ORIGIN>
 __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t *list, uint32_t n, const LaneRay &ray,
-                                           float &Lr, float &Lg, float &Lb, float &La)
+                                           float &Lr, float &Lg, float &Lb, float &La, uint32_t i_start = 0,
+                                           uint32_t i_step = EC)
 {
     Lr = Lg = Lb = La = 0.f;
     if (n == 0) return;
 
-    for (uint32_t i0 = 0; i0 < n; i0 += EC) {
+    for (uint32_t i0 = i_start; i0 < n; i0 += i_step) {
         // emitter chunk set-up
         float e_mubar[EC];
         float e_sigma[EC]; // wave-uniform
@@ -557,6 +559,7 @@ template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
 __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
                                                                 RenderTarget O)
 {
+    constexpr int DCAP = DW >= 16 ? vrtk::DCAP : 768; // 8-wave workgroups: two per CU must fit the 160 KB of LDS
     __shared__ uint32_t s_idx0[DCAP], s_idx[DCAP];   // "0": in list order; the others: sorted by depth
     __shared__ float4 s_A0[DCAP], s_B0[DCAP], s_A[DCAP], s_B[DCAP];
     __shared__ float s_key[DCAP];
@@ -657,8 +660,8 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
 
         float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
         if (cnt > DCAP) {
-            // does not fit LDS: one wave streams the list through scalar loads (any length)
-            if (wave == 0) shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La);
+            // does not fit LDS: every wave streams the whole list through scalar loads for its share of the emitters
+            shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La, wave * 4, DW * 4);
         } else {
             for (uint32_t i0 = wave * EC; i0 < cnt; i0 += DW * EC) {
                 float e_mubar[EC], e_sigma[EC];
