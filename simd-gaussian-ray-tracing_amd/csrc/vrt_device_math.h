@@ -99,20 +99,9 @@ __device__ __forceinline__ float vexp(float x)
 
 // ---- erf ------------------------------------------------------------------------------------
 
-// Abramowitz-Stegun 7.1.27 (approx.cpp:90-110): sign * (1 - 1/(1 + a0 t + a1 t^2 + a2 t^3 + a3 t^4)^4).
-// Returns A * erf_AS(x): the sign is moved onto the weight with one v_bfi, the reciprocal is
-// the 1-ulp v_rcp_f32 (the reference's SIMD path uses a 2^-14 estimate, its scalar path a divide).
-__device__ __forceinline__ float as_erf_weighted(float x, float A)
-{
-    const float t = __builtin_fabsf(x);
-    float p = __builtin_fmaf(0.078108f, t, 0.000972f);
-    p = __builtin_fmaf(p, t, 0.230389f);
-    p = __builtin_fmaf(p, t, 0.278393f);
-    p = __builtin_fmaf(p, t, 1.0f);
-    const float p2 = p * p;
-    const float rc = __builtin_amdgcn_rcpf(p2 * p2);
-    return __builtin_copysignf(A, x) * (1.0f - rc);
-}
+// Abramowitz-Stegun 7.1.27 (approx.cpp:90-110): sign * (1 - 1/(1 + a0 t + a1 t^2 + a2 t^3 + a3 t^4)^4): 4 fma +
+// 2 mul + the 1-ulp v_rcp_f32 (the reference's SIMD path uses a 2^-14 estimate, its scalar path a divide) + one
+// v_bfi for the sign.
 __device__ __forceinline__ float erf_as(float x)
 {
     const float t = __builtin_fabsf(x);
@@ -200,14 +189,6 @@ __host__ __device__ constexpr float erf_saturation()
 {
     return ERF == VRT_ERF_AS ? 5.5f : ERF == VRT_ERF_SPLINE ? 3.1f : ERF == VRT_ERF_SPLINE_MIRROR ? 2.9f
          : ERF == VRT_ERF_TAYLOR ? 2.0f : 4.2f;
-}
-
-// A * erf(x) -- the hot-loop form
-template <int ERF>
-__device__ __forceinline__ float verf_weighted(float x, float A)
-{
-    if constexpr (ERF == VRT_ERF_AS) return as_erf_weighted(x, A);
-    else return A * verf<ERF>(x);
 }
 
 } // namespace vrtk

@@ -1,25 +1,24 @@
-// vrt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the volumetric Gaussian
-// ray tracer.  No MFMA: the path is VALU + quarter-rate transcendental bound (one v_rcp_f32
-// per Abramowitz-Stegun erf term), fed by wave-uniform scalar loads.
+// vrt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the volumetric Gaussian ray tracer.
+// No MFMA: the path is VALU + quarter-rate transcendental bound (one v_rcp_f32 per Abramowitz-Stegun
+// erf term); Gaussian parameters reach the inner loops through LDS rows or wave-uniform scalar loads.
 //
 // Reference semantics (paths relative to /root/reference/src):
 //   L(ray) = sum_i albedo_i * sum_{k=-4..0} pdf_i(o + n s_ik) * T(s_ik) * sigma_i,
 //            s_ik = (mu_i - o).n + k sigma_i                               (vrt/rt.h:205-223)
 //   T(s)   = Exp( sum_j sigma_j cbar_j K (Erf(-mubar_j/(sqrt2 sigma_j)) - Erf((s - mubar_j)/(sqrt2 sigma_j))) )
 //            cbar_j = mag_j Exp(-(|oc_j|^2 - mubar_j^2)/(2 sigma_j^2)), K = 1/0.79788456  (vrt/rt.h:102-127)
-// evaluated by the reference with an O(5 N^2) double loop per ray that recomputes cbar_j,
-// mubar_j and Erf(-m_j) for every (i, k, j).  Here, per 8x8 pixel block (= one wavefront,
-// lane = ray):
-//   1. block cull: the block's rays form a cone; a tile Gaussian whose best-case
-//      sigma*mag*exp(-d^2/(2 sigma^2)) over the cone is < cull_eps is dropped
-//      (ballot + mbcnt compaction into an LDS index list).
-//   2. hoist: A_j = K sigma_j cbar_j, m_j = mubar_j r_j and E_j = Erf(-m_j) depend on the ray but
-//      not on the sample point, so
-//         T(s_ik) = Exp(sum_j A_j (E_j - Erf(s_ik r_j - m_j))).
-//   3. register blocking: EC emitters x 5 samples = 5*EC running sums per lane stream over
-//      the block's list once; per (ray, j) the (A_j, m_j) pair is recomputed (one exp) and
-//      amortised over the 5*EC erf terms, so nothing per-ray is ever stored.
-//      Gaussian parameters are wave-uniform: they arrive through scalar loads.
+// evaluated by the reference with an O(5 N^2) double loop per ray that recomputes cbar_j, mubar_j
+// and Erf(-m_j) for every (i, k, j).  Here:
+//   * culling in four levels -- reference tile (rt.cpp:29-69) ^ tile cone, 32x32-px cell cone, 8x8-px block
+//     cone (all conservative, `cone_keeps`), then the exact per-ray criterion sigma*mag*exp(-x) >= cull_eps;
+//   * hoisting -- A_j = K sigma_j cbar_j, m_j = mubar_j r_j and E_j = Erf(-m_j) depend on the ray but not on
+//     the sample point: T(s_ik) = Exp(sum_j A_j (E_j - Erf(s_ik r_j - m_j))), summed per term like the reference;
+//   * register blocking -- EC emitters x 5 samples = 5*EC running sums per lane while the absorbers stream by;
+//     (A_j, m_j, E_j) are recomputed per (ray, j, chunk) and amortised over the 5*EC terms, so nothing per-ray
+//     is ever stored;
+//   * two shading kernels -- one wavefront per 8x8 block with per-ray candidate lists (sparse scenes), one
+//     16-wave workgroup per block with depth-sorted candidates and exact saturation skipping (dense scenes).
+// DESIGN.md section 4 has the table of kernels and their measured costs.
 #include "vrt_kernels.h"
 #include "vrt_device_math.h"
 
