@@ -130,6 +130,10 @@ size_t vrt_hip_shard_pixels(const vrt_hip_ctx *ctx);
 int vrt_hip_render_shard_device(vrt_hip_ctx *ctx, const float origin[3], int pack_flags, uint32_t *d_shard,
                                 void *hip_stream);
 int vrt_hip_assemble_shards_device(vrt_hip_ctx *ctx, const uint32_t *d_gathered, uint32_t *d_image, void *hip_stream);
+/* Same, for gathers that carry several frames per rank ([rank][frame][shard]): rank r's shard of the frame to
+ * assemble starts at d_gathered + r * rank_stride_px (pass d_gathered already offset to the frame). */
+int vrt_hip_assemble_shards_strided_device(vrt_hip_ctx *ctx, const uint32_t *d_gathered, size_t rank_stride_px,
+                                           uint32_t *d_image, void *hip_stream);
 
 /* -------- point queries: replace transmittance / radiance (rt.h:32-54, 146-223) ----------- */
 /* T_out[k] = transmittance<Exp,Erf>(o, n, s[k], all Gaussians of the scene), rt.h:32-54. */

@@ -68,6 +68,7 @@ SYMBOLS = {
     "vrt_hip_shard_pixels": (C.c_size_t, [_vp]),
     "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
     "vrt_hip_assemble_shards_device": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "vrt_hip_assemble_shards_strided_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "vrt_hip_transmittance": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, _f32p]),
     "vrt_hip_radiance": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p]),
     "vrt_hip_transmittance_step": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, C.c_float, _f32p]),
@@ -246,9 +247,14 @@ class Renderer:
         self._chk(self._L.vrt_hip_render_shard_device(self._h, _fp(_f3(origin)), pack, d_shard, stream or None),
                   "render_shard_device")
 
-    def assemble_shards_device(self, d_gathered, d_image, stream=0):
-        self._chk(self._L.vrt_hip_assemble_shards_device(self._h, d_gathered, d_image, stream or None),
-                  "assemble_shards_device")
+    def assemble_shards_device(self, d_gathered, d_image, stream=0, rank_stride_px=None):
+        """Scatter a rank-major gather result into raster order; rank_stride_px > shard_pixels() when the gather
+        carried several frames per rank (d_gathered then points at the frame's slice of rank 0)."""
+        if rank_stride_px is None:
+            rc = self._L.vrt_hip_assemble_shards_device(self._h, d_gathered, d_image, stream or None)
+        else:
+            rc = self._L.vrt_hip_assemble_shards_strided_device(self._h, d_gathered, rank_stride_px, d_image, stream or None)
+        self._chk(rc, "assemble_shards_device")
 
     # ---- point queries ----
     def transmittance(self, o, n, s):

@@ -871,17 +871,26 @@ int vrt_hip_render_shard_device(vrt_hip_ctx *c, const float origin[3], int pack_
     return render_common(c, origin, pack_flags, d_shard, nullptr, (hipStream_t)hip_stream, true);
 }
 
-int vrt_hip_assemble_shards_device(vrt_hip_ctx *c, const uint32_t *d_gathered, uint32_t *d_image, void *hip_stream)
+int vrt_hip_assemble_shards_strided_device(vrt_hip_ctx *c, const uint32_t *d_gathered, size_t rank_stride_px,
+                                           uint32_t *d_image, void *hip_stream)
 {
     if (!c || !d_gathered || !d_image) return VRT_HIP_ERR_INVALID;
     int rc = check_ready(c);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = rebuild_shard(c))) return rc;
-    launch_assemble(d_gathered, d_image, c->slot_tiles.p, c->n_slots * (uint32_t)c->world, tile_geometry(c), c->w, c->h,
+    const TileLists t = tile_geometry(c);
+    if (rank_stride_px < (size_t)c->n_slots * t.tile_w * t.tile_h) return fail(c, VRT_HIP_ERR_INVALID, "assemble: rank stride smaller than one shard");
+    launch_assemble(d_gathered, d_image, c->slot_tiles.p, c->n_slots, (uint32_t)c->world, rank_stride_px, t, c->w, c->h,
                     (hipStream_t)hip_stream);
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;
+}
+
+int vrt_hip_assemble_shards_device(vrt_hip_ctx *c, const uint32_t *d_gathered, uint32_t *d_image, void *hip_stream)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    return vrt_hip_assemble_shards_strided_device(c, d_gathered, vrt_hip_shard_pixels(c), d_image, hip_stream);
 }
 
 // ---- point queries ------------------------------------------------------------------------------

@@ -121,8 +121,8 @@ struct FuseArgs {
     RenderTarget O;
 };
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st);
-void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t n_slots,
-                     const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
+void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,
+                     uint32_t world, uint64_t rank_stride, const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
 void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);
 
 // point queries

@@ -1146,30 +1146,32 @@ void launch_build_cell_lists(const SceneTables &s, const TileLists &t, const Cel
                        n_cells, refine);
 }
 
-// scatter rank-major shard buffers [slot][tile_h][tile_w] into the raster image (rt.h:388-399)
+// scatter rank-major shard buffers [rank](stride rank_stride)[slot][tile_h][tile_w] into the raster image (rt.h:388-399)
 __global__ void assemble_kernel(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, TileLists T,
-                                uint32_t width, uint32_t height)
+                                uint32_t width, uint32_t height, uint32_t slots_per_rank, uint64_t rank_stride)
 {
     const uint32_t slot = blockIdx.y;
     const uint32_t t = tile_of_slot[slot];
     if (t == 0xFFFFFFFFu) return;
+    const uint32_t *src = gathered + (slot / slots_per_rank) * rank_stride + (size_t)(slot % slots_per_rank) * (T.tile_w * T.tile_h);
     const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
     const uint32_t per_tile = T.tile_w * T.tile_h;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < per_tile; p += gridDim.x * blockDim.x) {
         const uint32_t lx = p % T.tile_w, ly = p / T.tile_w;
         const uint64_t pix = (uint64_t)(tx * T.tile_w + lx) + (uint64_t)T.stride * (ty * T.tile_h + ly);
-        if (pix < (uint64_t)width * height) image[pix] = gathered[(size_t)slot * per_tile + p];
+        if (pix < (uint64_t)width * height) image[pix] = src[p];
     }
 }
 
-void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t n_slots,
-                     const TileLists &t, uint32_t width, uint32_t height, hipStream_t st)
+void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,
+                     uint32_t world, uint64_t rank_stride, const TileLists &t, uint32_t width, uint32_t height, hipStream_t st)
 {
+    const uint32_t n_slots = slots_per_rank * world;
     if (!n_slots) return;
     const uint32_t per_tile = t.tile_w * t.tile_h;
     const uint32_t gx = min((per_tile + 255u) / 256u, 64u);
     hipLaunchKernelGGL(assemble_kernel, dim3(gx ? gx : 1, n_slots), dim3(256), 0, st, gathered, image, tile_of_slot, t,
-                       width, height);
+                       width, height, slots_per_rank, rank_stride);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -283,6 +283,17 @@ def test_sharded_render_assembles_to_full_frame(pkg, oracle, renderer):
         renderer.assemble_shards_device(gathered.data_ptr(), out.data_ptr(), st)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full)
+        # several frames per gather: [rank][frame][shard], frame 1 of 3 holds the image, the others garbage
+        n, frames = shards[0].numel(), 3
+        batched = torch.full((world, frames, n), 0x7F7F7F7F, dtype=torch.int32, device="cuda")
+        for rank in range(world):
+            batched[rank, 1] = shards[rank]
+        out.zero_()
+        renderer.assemble_shards_device(batched.data_ptr() + 4 * n, out.data_ptr(), st, rank_stride_px=frames * n)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full)
+        with pytest.raises(RuntimeError):
+            renderer.assemble_shards_device(batched.data_ptr(), out.data_ptr(), st, rank_stride_px=n - 1)
     renderer.set_shard(0, 1)
 
 
