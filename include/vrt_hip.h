@@ -164,6 +164,7 @@ typedef struct {
     uint64_t lane_max_entries;/* sum over blocks of the longest per-ray list (the loop trip count)    */
     uint64_t shaded_blocks;  /* blocks that reached the shading loops (the rest were only cleared)    */
     uint64_t dense_blocks;   /* of those, blocks shaded by the 16-waves-per-block kernel              */
+    double dense_busy_frac;  /* mean share of that kernel's duration its workgroups had blocks to work on */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

@@ -33,7 +33,8 @@ class VrtHipError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("tiling_ms", C.c_double), ("rays", C.c_uint64), ("blocks", C.c_uint64),
                 ("list_entries", C.c_uint64), ("tile_entries", C.c_uint64), ("overflow_blocks", C.c_uint64),
-                ("lane_entries", C.c_uint64), ("lane_max_entries", C.c_uint64), ("shaded_blocks", C.c_uint64), ("dense_blocks", C.c_uint64)]
+                ("lane_entries", C.c_uint64), ("lane_max_entries", C.c_uint64), ("shaded_blocks", C.c_uint64), ("dense_blocks", C.c_uint64),
+                ("dense_busy_frac", C.c_double)]
 
 
 def build(verbose=False):

@@ -72,7 +72,7 @@ struct vrt_hip_ctx {
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
     // second level: 32x32-pixel cells of the local tiles + the active/inactive queues of the render kernel
-    DevBuf<uint32_t> c_count, c_indices, c_active, c_inactive, c_dense, c_overflow, c_counters;
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_inactive, c_dense, c_dense_sorted, c_overflow, c_counters;
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
     int lists_for_shard = -1; // sharding mode the cell lists were built for
     bool lists_fresh = false; // the queue counters were zeroed by the list build of this very call
@@ -299,7 +299,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
     g.cells_x = c->cells_x; g.cells_y = c->cells_y; g.cstride = c->cstride;
     g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.inactive = c->c_inactive.p;
-    g.dense = c->c_dense.p;
+    g.dense = c->c_dense.p; g.dense_sorted = c->c_dense_sorted.p;
     g.n_active = cnt; g.n_inactive = cnt + 1; g.n_dense = cnt + 2;
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
@@ -332,6 +332,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     c->cstride = std::max(1u, std::min(c->n, 4096u));
     HIPCHK(c, c->c_count.reserve(c->n_cells)); HIPCHK(c, c->c_active.reserve(c->n_cells));
     HIPCHK(c, c->c_inactive.reserve(c->n_cells)); HIPCHK(c, c->c_dense.reserve(c->n_cells));
+    HIPCHK(c, c->c_dense_sorted.reserve(c->n_cells));
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
     if (!c->c_counters.p) {
@@ -471,7 +472,10 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     }
     if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
     const TileLists t = work_lists(c);
-    if (o.stats) HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 8 * sizeof(unsigned long long), st));
+    if (o.stats) {
+        HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 12 * sizeof(unsigned long long), st));
+        HIPCHK(c, hipMemsetAsync(c->d_stats.p + 8, 0xFF, sizeof(unsigned long long), st)); // running minimum
+    }
     const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
     c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
@@ -497,6 +501,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
     // dense queue: one 16-wave workgroup per CU pulls blocks until the queue is empty (exits at once if it is)
+    if (launch_dense) launch_order_dense(cg, st);
     if (launch_dense)
         launch_render_dense(tables(c), t, cg, ray_gen(c, origin), o,
                             (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16))),
@@ -564,7 +569,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        c->d_stats.reserve(8) != hipSuccess) {
+        c->d_stats.reserve(12) != hipSuccess) {
         delete c;
         return fail(nullptr, VRT_HIP_ERR_HIP, "create: stream/event creation failed");
     }
@@ -581,7 +586,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
-    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_overflow.release(); c->c_counters.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_overflow.release(); c->c_counters.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
@@ -836,8 +841,9 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
     if (c->stats_on) {
-        unsigned long long st[7];
+        unsigned long long st[12];
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
+        c->last.dense_busy_frac = (st[11] && st[9] > st[8]) ? (double)st[10] / ((double)st[11] * (double)(st[9] - st[8])) : 0.0;
         c->last.shaded_blocks = st[5] + st[6];
         c->last.dense_blocks = st[6];
         c->last.list_entries = st[0]; c->last.tile_entries = st[1]; c->last.overflow_blocks = st[2];

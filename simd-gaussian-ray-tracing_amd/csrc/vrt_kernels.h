@@ -42,6 +42,7 @@ struct CellGrid {
     uint32_t *indices;               // cell c at indices + c*cstride
     uint32_t *active, *inactive;     // cell ids: shaded one wavefront per block / only cleared
     uint32_t *dense;                 // cell ids with long lists: shaded one 16-wave workgroup per block
+    uint32_t *dense_sorted;          // the same, longest list first (order_dense_kernel): the queue order of the dense kernel
     uint32_t *n_active, *n_inactive, *n_dense; // device counters, zeroed before build_cell_lists_kernel
     uint32_t *dense_next;            // work counter of the dense kernel (zeroed with the others)
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
@@ -87,6 +88,7 @@ void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, 
 void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int dw /* waves per block: 4, 8 or 16 */, int exp_kind,
                          int erf_kind, hipStream_t st);
+void launch_order_dense(const CellGrid &c, hipStream_t st);
 void launch_build_cell_lists(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                              const uint32_t *tile_map, uint32_t n_cells, int refine, hipStream_t st);
 

@@ -558,9 +558,9 @@ template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
 __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
                                                                 RenderTarget O)
 {
-    constexpr int DCAP = DW >= 16 ? vrtk::DCAP : 768; // 8-wave workgroups: two per CU must fit the 160 KB of LDS
+    constexpr int DCAP = vrtk::DCAP;
     __shared__ uint32_t s_idx0[DCAP], s_idx[DCAP];   // "0": in list order; the others: sorted by depth
-    __shared__ float4 s_A0[DCAP], s_B0[DCAP], s_A[DCAP], s_B[DCAP];
+    __shared__ float4 s_A[DCAP], s_B[DCAP];          // 60 KB with the rest: two 8-wave workgroups fit a CU's 160 KB
     __shared__ float s_key[DCAP];
     __shared__ float4 s_L[DW][64];
     __shared__ uint32_t s_wave_cnt[DW];
@@ -571,15 +571,23 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
     constexpr float SAT_M = SAT + 1e-3f; // the range bounds are re-associated forms of the arguments: keep a margin
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
     if (C.feedback && blockIdx.x == 0 && tid == 0) C.feedback[2] = n_items;
+    const unsigned long long t_start = O.stats ? wall_clock64() : 0ull;
 
     for (;;) {
         __syncthreads(); // everyone is done with the previous item's LDS
         if (tid == 0) s_item = atomicAdd(C.dense_next, 1u);
         __syncthreads();
         const uint32_t item = s_item;
-        if (item >= n_items) break;
+        if (item >= n_items) {
+            if (O.stats && tid == 0) { // workgroup timeline: how long the queue kept this workgroup busy
+                const unsigned long long t_end = wall_clock64();
+                atomicMin(&O.stats[8], t_start); atomicMax(&O.stats[9], t_end);
+                atomicAdd(&O.stats[10], t_end - t_start); atomicAdd(&O.stats[11], 1ull);
+            }
+            break;
+        }
         uint32_t cell, bi;
-        if (item < n_dense16) { cell = C.dense[item >> 4]; bi = item & 15u; }
+        if (item < n_dense16) { cell = C.dense_sorted[item >> 4]; bi = item & 15u; }
         else { const uint32_t packed = C.overflow[item - n_dense16]; cell = packed >> 4; bi = packed & 15u; }
         const BlockPos p = block_of(T, C, O, cell, bi, lane);
         if (!p.inside) continue;
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
             }
             const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
             if (keep && pos < DCAP) {
-                s_idx0[pos] = idx; s_A0[pos] = a; s_B0[pos] = bq;
+                s_idx0[pos] = idx;
                 s_key[pos] = a.x * cone.cx + a.y * cone.cy + a.z * cone.cz; // depth along the block's axis
             }
             cnt += chunk;
@@ -646,7 +654,8 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                     const float kk = s_key[k];
                     r += (kk < ki || (kk == ki && k < i)) ? 1u : 0u;
                 }
-                s_idx[r] = s_idx0[i]; s_A[r] = s_A0[i]; s_B[r] = s_B0[i];
+                const uint32_t idx = s_idx0[i];
+                s_idx[r] = idx; s_A[r] = S.gA[idx]; s_B[r] = S.gB[idx]; // rows come back from L2 (read a moment ago)
             }
         }
         __syncthreads();
@@ -754,6 +763,39 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
             if (O.radiance) O.radiance[out] = sum;
         }
     }
+}
+
+// Queue order of the dense kernel: cells by descending candidate count (a block costs ~ count^2), so that the
+// blocks still running when the queue empties are the cheapest ones.  Counting sort, one workgroup.
+__global__ __launch_bounds__(1024) void order_dense_kernel(CellGrid C)
+{
+    __shared__ uint32_t s_hist[1024], s_scan[1024];
+    const uint32_t n = *C.n_dense, tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[1023u - (min(C.count[C.dense[i]], 4095u) >> 2)], 1u);
+    __syncthreads();
+    // exclusive prefix over the buckets (bucket 0 = longest lists)
+    uint32_t v = s_hist[tid];
+    s_scan[tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+    }
+    s_hist[tid] = s_scan[tid] - v;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t cell = C.dense[i];
+        C.dense_sorted[atomicAdd(&s_hist[1023u - (min(C.count[cell], 4095u) >> 2)], 1u)] = cell;
+    }
+}
+
+void launch_order_dense(const CellGrid &c, hipStream_t st)
+{
+    hipLaunchKernelGGL(order_dense_kernel, dim3(1), dim3(1024), 0, st, c);
 }
 
 template <int EXP, int ERF>
