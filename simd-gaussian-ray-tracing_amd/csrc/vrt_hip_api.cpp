@@ -12,7 +12,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -72,7 +74,9 @@ struct vrt_hip_ctx {
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
     // second level: 32x32-pixel cells of the local tiles + the active/inactive queues of the render kernel
-    DevBuf<uint32_t> c_count, c_indices, c_active, c_inactive, c_dense, c_dense_sorted, c_overflow, c_counters;
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_inactive, c_dense, c_dense_sorted, c_overflow, c_counters, c_rq;
+    uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
+    int render_waves_per_cu = 12; // persistent one-wave workgroups per CU (LDS allows 13); VRT_HIP_RENDER_WAVES overrides
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
     int lists_for_shard = -1; // sharding mode the cell lists were built for
     bool lists_fresh = false; // the queue counters were zeroed by the list build of this very call
@@ -114,7 +118,8 @@ struct vrt_hip_ctx {
     // scratch + statistics
     DevBuf<uint32_t> d_image;
     DevBuf<float4> d_rad;
-    DevBuf<unsigned long long> d_stats;
+    DevBuf<unsigned long long> d_stats, d_timeline; // d_timeline: VRT_HIP_TIMELINE=1 diagnostics
+    size_t timeline_items = 0;
     bool stats_on = false;
     vrt_hip_stats last{};
     // kernel timing ring (vrt_hip_enable_kernel_timing)
@@ -124,6 +129,7 @@ struct vrt_hip_ctx {
     uint64_t timing_count = 0;
 };
 
+static void print_timeline(vrt_hip_ctx *c);
 namespace {
 
 int fail(vrt_hip_ctx *c, int code, const std::string &msg)
@@ -476,11 +482,18 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 12 * sizeof(unsigned long long), st));
         HIPCHK(c, hipMemsetAsync(c->d_stats.p + 8, 0xFF, sizeof(unsigned long long), st)); // running minimum
     }
+    c->timeline_items = 0;
+    if (getenv("VRT_HIP_TIMELINE")) {
+        c->timeline_items = (size_t)c->n_cells * 16;
+        HIPCHK(c, c->d_timeline.reserve(c->timeline_items * 5));
+        HIPCHK(c, hipMemsetAsync(c->d_timeline.p, 0, c->timeline_items * 5 * sizeof(unsigned long long), st));
+        o.timeline = c->d_timeline.p;
+    }
     const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
     c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
     // persistent grid: 16 wavefronts per CU (LDS- and VGPR-limited residency), never more than there are blocks
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * 16u);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * c->render_waves_per_cu);
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
         HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1) + 3, 0, 2 * sizeof(uint32_t), st));
     c->lists_fresh = false;
@@ -497,6 +510,13 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     c->dense_launched_last = launch_dense;
     CellGrid cg = cell_grid(c);
     cg.no_dense = launch_dense ? 0 : 1;
+    if (!c->c_rq.p) {
+        HIPCHK(c, c->c_rq.reserve(2 * RQ_N * RQ_STRIDE));
+        HIPCHK(c, hipMemsetAsync(c->c_rq.p, 0, 2 * RQ_N * RQ_STRIDE * sizeof(uint32_t), st));
+    }
+    ++c->rq_gen;
+    cg.rq = c->c_rq.p + (c->rq_gen & 1) * RQ_N * RQ_STRIDE;
+    cg.rq_next = c->c_rq.p + ((c->rq_gen + 1) & 1) * RQ_N * RQ_STRIDE;
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
     launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
@@ -563,6 +583,10 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
             (void)hipHostFree(hp);
         }
     }
+    if (const char *e = getenv("VRT_HIP_RENDER_WAVES")) { // one-wave kernel: persistent waves per CU (tuning knob)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
+    }
     if (const char *e = getenv("VRT_HIP_DENSE_WAVES")) {
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 17) c->dense_waves = v; // 17 = 16 waves without saturation skipping (A/B)
@@ -586,9 +610,9 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
-    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_overflow.release(); c->c_counters.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_overflow.release(); c->c_counters.release(); c->c_rq.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
-    c->d_image.release(); c->d_rad.release(); c->d_stats.release();
+    c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
     for (auto &e : c->tev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -849,9 +873,55 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
         c->last.list_entries = st[0]; c->last.tile_entries = st[1]; c->last.overflow_blocks = st[2];
         c->last.lane_entries = st[3]; c->last.lane_max_entries = st[4];
     }
+    if (c->timeline_items) print_timeline(c);
     if (image_out) HIPCHK(c, hipMemcpy(image_out, c->d_image.p, npix * 4, hipMemcpyDeviceToHost));
     if (radiance_out) HIPCHK(c, hipMemcpy(radiance_out, c->d_rad.p, npix * 16, hipMemcpyDeviceToHost));
     return VRT_HIP_OK;
+}
+
+// VRT_HIP_TIMELINE=1: where the one-wave kernel's time goes (wall_clock64 ticks are 10 ns), printed by vrt_hip_render()
+static void print_timeline(vrt_hip_ctx *c)
+{
+    std::vector<unsigned long long> tl(c->timeline_items * 5);
+    if (hipMemcpy(tl.data(), c->d_timeline.p, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double n = 0, s_start = 0, s_end = 0, p0 = 0, p1 = 0, p2 = 0;
+    for (size_t i = 0; i < c->timeline_items; ++i)
+        if (tl[5 * i + 3]) { t0 = std::min(t0, tl[5 * i]); t1 = std::max(t1, tl[5 * i + 3]); }
+    std::vector<unsigned> starts(64, 0), ends(64, 0);
+    std::map<uint32_t, std::pair<int, double>> per_simd; // blocks, last end (us)
+    std::map<uint32_t, int> per_cu;
+    for (size_t i = 0; i < c->timeline_items; ++i) {
+        const unsigned long long *e = &tl[5 * i];
+        if (!e[3]) continue;
+        {   // gfx9 HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID [3:0]
+            const uint32_t hw = (uint32_t)e[4], xcc = (uint32_t)(e[4] >> 32) & 15u;
+            const uint32_t cu = (xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            const uint32_t simd = (cu << 2) | ((hw >> 4) & 3u);
+            auto &a = per_simd[simd]; a.first += 1; a.second = std::max(a.second, (double)(e[3] - t0) * 0.01);
+            per_cu[cu] += 1;
+        }
+        n += 1; s_start += (double)(e[0] - t0); s_end += (double)(e[3] - t0);
+        p0 += (double)(e[1] - e[0]); p1 += (double)(e[2] - e[1]); p2 += (double)(e[3] - e[2]);
+        const double span = (double)(t1 - t0) + 1;
+        ++starts[(size_t)((e[0] - t0) * 64.0 / span)]; ++ends[(size_t)((e[3] - t0) * 64.0 / span)];
+    }
+    if (n == 0) return;
+    fprintf(stderr, "[vrt_hip] one-wave kernel timeline: %.0f blocks, span %.2f us, mean start %.2f us, mean end %.2f us; per block: "
+                    "block cull %.2f us, lane lists %.2f us, shade+store %.2f us\n[vrt_hip]   running blocks per 1/64 of the span:",
+            n, (t1 - t0) * 0.01, s_start / n * 0.01, s_end / n * 0.01, p0 / n * 0.01, p1 / n * 0.01, p2 / n * 0.01);
+    long running = 0;
+    for (int b = 0; b < 64; ++b) { running += starts[b]; fprintf(stderr, " %ld", running); running -= ends[b]; }
+    fprintf(stderr, "\n");
+    std::map<int, std::pair<int, double>> by_count; // blocks on a SIMD -> (SIMDs, mean last end)
+    for (auto &kv : per_simd) { auto &b = by_count[kv.second.first]; b.first += 1; b.second += kv.second.second; }
+    fprintf(stderr, "[vrt_hip]   %zu CUs, %zu SIMDs seen; blocks per SIMD -> SIMDs (mean time of their last block end):", per_cu.size(), per_simd.size());
+    for (auto &kv : by_count) fprintf(stderr, "  %d -> %d (%.1f us)", kv.first, kv.second.first, kv.second.second / kv.second.first);
+    std::map<int, int> cu_hist;
+    for (auto &kv : per_cu) cu_hist[kv.second] += 1;
+    fprintf(stderr, "\n[vrt_hip]   blocks per CU -> CUs:");
+    for (auto &kv : cu_hist) fprintf(stderr, "  %d -> %d", kv.first, kv.second);
+    fprintf(stderr, "\n");
 }
 
 int vrt_hip_set_shard(vrt_hip_ctx *c, int rank, int world)

@@ -11,7 +11,7 @@ constexpr int BLOCK_H = 8;
 constexpr int CELL = 32;          // second-level cull region: 32x32 pixels = 4x4 blocks
 constexpr int TCAP = 1024;        // a tile's candidates kept in LDS by the fused list kernel
 constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate cell kernel (one wave per cell)
-constexpr int PCAP = 192;         // per-block candidates cached in LDS (index + two parameter rows = 36 B each)
+constexpr int PCAP = 128;         // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each)
 constexpr int DCAP = 1024;        // per-block candidates the dense kernel keeps in LDS
 constexpr int PL = 48;            // per-lane list capacity (u8 positions into the block's candidates)
 
@@ -54,7 +54,12 @@ struct CellGrid {
     // one-wave kernel that no dense kernel follows, so it must shade everything itself.
     uint32_t *feedback;
     int no_dense;
+    // Work queues of the one-wave kernel: a wave's first block is static (item = wave), the blocks beyond the grid size
+    // are pulled from RQ_N counters RQ_STRIDE words apart (item G + q + RQ_N*m is the m-th of queue q).  `rq` is this
+    // launch's set (zero on entry), `rq_next` the other set, which this launch clears for the next one.
+    uint32_t *rq, *rq_next;
 };
+constexpr uint32_t RQ_N = 8, RQ_STRIDE = 64;
 
 struct RayGen {
     const float *xs, *ys, *zs; // plane arrays (nullptr => basis mode)
@@ -76,6 +81,7 @@ struct RenderTarget {
     int cleared;              // inactive cells were already cleared by the list kernel of this frame
     unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
                                // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
+    unsigned long long *timeline; // nullable diagnostics: 4 wall_clock64 stamps + the hardware id per one-wave work item (5 words)
 };
 
 void launch_prep_frame(const SceneTables &s, float4 *gA_out, const float origin[3], hipStream_t st);

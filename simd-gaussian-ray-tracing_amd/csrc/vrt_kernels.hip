@@ -205,82 +205,97 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
 // its block's candidates, and the pair loop is quadratic in the list length.  All lanes run the loops to
 // the longest lane list; a lane past the end of its list adds exact zeros (A = 0).
 // ---------------------------------------------------------------------------------------------
+// One chunk of EC emitters (list positions i0 .. i0+EC-1 of every lane) against the lane's whole list.
 template <int EXP, int ERF, int EC>
-__device__ __forceinline__ void shade_lanes(const SceneTables &S, const uint32_t *s_idx, const float4 *s_A,
-                                            const float4 *s_B, const uint8_t *s_lane /*[k*64 + lane]*/, uint32_t nl,
+__device__ __forceinline__ void shade_chunk(const float4 *s_A, const float4 *s_B, const float4 *s_M, const float4 *s_C,
+                                            const float *s_q, const uint8_t *s_lane /*[k*64 + lane]*/, uint32_t nl,
+                                            uint32_t nmax, uint32_t lane, const LaneRay &ray, uint32_t i0, float &Lr,
+                                            float &Lg, float &Lb, float &La)
+{
+    float e_mubar[EC], e_sigma[EC];
+    uint32_t e_li[EC];
+#pragma unroll
+    for (int e = 0; e < EC; ++e) {
+        const bool ve = i0 + e < nl;
+        e_li[e] = ve ? s_lane[(i0 + e) * 64 + lane] : 0u;
+        const float4 a = s_A[e_li[e]];
+        e_mubar[e] = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+        e_sigma[e] = s_M[e_li[e]].w;
+    }
+    float acc[EC][5];
+#pragma unroll
+    for (int e = 0; e < EC; ++e)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[e][k] = 0.f;
+
+    // absorber stream over this lane's list; next entry's LDS rows are fetched one iteration ahead
+    uint32_t lj = nl ? s_lane[lane] : 0u;
+    float4 a = s_A[lj], b = s_B[lj];
+    for (uint32_t j = 0; j < nmax; ++j) {
+        const float4 ca = a, cb = b;
+        const bool vj = j < nl;
+        if (j + 1 < nmax) {
+            lj = (j + 1 < nl) ? s_lane[(j + 1) * 64 + lane] : 0u;
+            a = s_A[lj]; b = s_B[lj];
+        }
+        const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+        const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+        const float A = vj ? cb.z * vexp<EXP>(-(d2 * cb.y)) : 0.f;
+        const float m = mubar * cb.x;
+        const float E = verf<ERF>(-m);
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            const float base = __builtin_fmaf(e_mubar[e], cb.x, -m);
+            const float step = e_sigma[e] * cb.x;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float x = __builtin_fmaf((float)(k - 4), step, base);
+                acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
+            }
+        }
+    }
+
+    // emission (see shade_list)
+#pragma unroll
+    for (int e = 0; e < EC; ++e) {
+        if (i0 + e < nl) {
+            const float4 ms = s_M[e_li[e]];
+            const float inv2s2 = s_B[e_li[e]].y;
+            const float q = s_q[e_li[e]];
+            float inner = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[e]);
+                const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
+                const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
+                const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
+                const float dd = dot3_ref(px, py, pz, px, py, pz);
+                inner += emission_term<EXP>(q, dd * inv2s2, acc[e][k]);
+            }
+            const float4 alb = s_C[e_li[e]];
+            Lr = __builtin_fmaf(alb.x, inner, Lr);
+            Lg = __builtin_fmaf(alb.y, inner, Lg);
+            Lb = __builtin_fmaf(alb.z, inner, Lb);
+            La = __builtin_fmaf(alb.w, inner, La);
+        }
+    }
+}
+
+// Chunks of EC emitters, then one chunk of exactly the remaining 1..EC-1: the pair loop costs nmax^2, not
+// nmax * (nmax rounded up to a multiple of EC).
+template <int EXP, int ERF, int EC>
+__device__ __forceinline__ void shade_lanes(const float4 *s_A, const float4 *s_B, const float4 *s_M, const float4 *s_C,
+                                            const float *s_q, const uint8_t *s_lane /*[k*64 + lane]*/, uint32_t nl,
                                             uint32_t nmax, uint32_t lane, const LaneRay &ray, float &Lr, float &Lg,
-                                            float &Lb, float &La)
+                                            float &Lb, float &La, uint32_t i_start = 0, uint32_t i_step = EC)
 {
     Lr = Lg = Lb = La = 0.f;
-    for (uint32_t i0 = 0; i0 < nmax; i0 += EC) {
-        float e_mubar[EC], e_sigma[EC];
-        uint32_t e_li[EC];
-#pragma unroll
-        for (int e = 0; e < EC; ++e) {
-            const bool ve = i0 + e < nl;
-            e_li[e] = ve ? s_lane[(i0 + e) * 64 + lane] : 0u;
-            const float4 a = s_A[e_li[e]];
-            e_mubar[e] = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
-            e_sigma[e] = S.gD[s_idx[e_li[e]]].x;
-        }
-        float acc[EC][5];
-#pragma unroll
-        for (int e = 0; e < EC; ++e)
-#pragma unroll
-            for (int k = 0; k < 5; ++k) acc[e][k] = 0.f;
-
-        // absorber stream over this lane's list; next entry's LDS rows are fetched one iteration ahead
-        uint32_t lj = nl ? s_lane[lane] : 0u;
-        float4 a = s_A[lj], b = s_B[lj];
-        for (uint32_t j = 0; j < nmax; ++j) {
-            const float4 ca = a, cb = b;
-            const bool vj = j < nl;
-            if (j + 1 < nmax) {
-                lj = (j + 1 < nl) ? s_lane[(j + 1) * 64 + lane] : 0u;
-                a = s_A[lj]; b = s_B[lj];
-            }
-            const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
-            const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
-            const float A = vj ? cb.z * vexp<EXP>(-(d2 * cb.y)) : 0.f;
-            const float m = mubar * cb.x;
-            const float E = verf<ERF>(-m);
-#pragma unroll
-            for (int e = 0; e < EC; ++e) {
-                const float base = __builtin_fmaf(e_mubar[e], cb.x, -m);
-                const float step = e_sigma[e] * cb.x;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const float x = __builtin_fmaf((float)(k - 4), step, base);
-                    acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
-                }
-            }
-        }
-
-        // emission (see shade_list)
-#pragma unroll
-        for (int e = 0; e < EC; ++e) {
-            if (i0 + e < nl) {
-                const uint32_t idx = s_idx[e_li[e]];
-                const float4 ms = S.mu_sig[idx];
-                const float inv2s2 = s_B[e_li[e]].y;
-                const float q = S.gD[idx].y;
-                float inner = 0.f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[e]);
-                    const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
-                    const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
-                    const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
-                    const float dd = dot3_ref(px, py, pz, px, py, pz);
-                    inner += emission_term<EXP>(q, dd * inv2s2, acc[e][k]);
-                }
-                const float4 alb = S.gC[idx];
-                Lr = __builtin_fmaf(alb.x, inner, Lr);
-                Lg = __builtin_fmaf(alb.y, inner, Lg);
-                Lb = __builtin_fmaf(alb.z, inner, Lb);
-                La = __builtin_fmaf(alb.w, inner, La);
-            }
-        }
+    for (uint32_t i0 = i_start; i0 < nmax; i0 += i_step) {
+        const uint32_t rem = nmax - i0;
+        if (rem >= (uint32_t)EC) shade_chunk<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else if (EC > 3 && rem == 3) shade_chunk<EXP, ERF, 3>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else if (EC > 2 && rem == 2) shade_chunk<EXP, ERF, 2>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else shade_chunk<EXP, ERF, 1>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
     }
 }
 
@@ -409,8 +424,10 @@ __device__ __forceinline__ BlockPos block_of(const TileLists &T, const CellGrid 
 template <int EXP, int ERF, int EC>
 __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
 {
-    __shared__ uint32_t s_idx[PCAP];
-    __shared__ float4 s_A[PCAP], s_B[PCAP];
+    // every row a kept candidate needs later (absorber: A, B; emitter: mu/sigma, albedo, sigma*mag) is fetched in the one
+    // round trip of the block cull: the shading loops then run out of LDS only
+    __shared__ float4 s_A[PCAP], s_B[PCAP], s_M[PCAP], s_C[PCAP];
+    __shared__ float s_q[PCAP];
     __shared__ uint8_t s_lane[PL * 64];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x, G = gridDim.x;
     const uint64_t npix = (uint64_t)R.width * R.height;
@@ -441,7 +458,34 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     }
 
     // ---- shade ----
-    for (uint32_t item = wave; item < n_shade; item += G) {
+    if (wave == 0 && lane < RQ_N) C.rq_next[lane * RQ_STRIDE] = 0;
+    const uint32_t n_dyn = n_shade > G ? n_shade - G : 0u;
+    uint32_t rq_tries = 0;
+    // next block: blocks cost between ~1 and ~30 units (the pair loops are quadratic in the per-ray list length), so
+    // after its static first block a wave pulls more from the queues, its own first, until all are empty
+    auto next_item = [&]() -> uint32_t {
+        while (rq_tries < RQ_N) {
+            const uint32_t q = (wave + rq_tries) % RQ_N;
+            const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
+            uint32_t m = 0xFFFFFFFFu;
+            if (lane == 0 && per) {
+                uint32_t *ctr = C.rq + q * RQ_STRIDE;
+                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) m = atomicAdd(ctr, 1u);
+            }
+            m = __builtin_amdgcn_readfirstlane(m);
+            if (m < per) return G + q + RQ_N * m;
+            ++rq_tries;
+        }
+        return 0xFFFFFFFFu;
+    };
+    auto write_block = [&](float Lr, float Lg, float Lb, float La, bool valid, uint64_t out) {
+        if (valid) {
+            if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
+            if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
+        }
+    };
+    for (uint32_t item = wave; item < n_shade; item = next_item()) {
+        const unsigned long long tl0 = O.timeline ? wall_clock64() : 0ull; // diagnostics (VRT_HIP_TIMELINE runs only)
         const uint32_t ci = item >> 4;
         const uint32_t cell = ci < n_active ? C.active[ci] : C.dense[ci - n_active];
         const BlockPos p = block_of(T, C, O, cell, item & 15u, lane);
@@ -478,20 +522,21 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
         for (uint32_t base = 0; base < n_list; base += 64) {
             const uint32_t k = base + lane;
             bool keep = false;
-            uint32_t idx = 0;
-            float4 a, bq;
+            float4 a, bq, ms, alb;
+            float q;
             if (k < n_list) {
-                idx = list[k];
-                a = S.gA[idx]; bq = S.gB[idx];
+                const uint32_t idx = list[k];
+                a = S.gA[idx]; bq = S.gB[idx]; ms = S.mu_sig[idx]; alb = S.gC[idx]; q = S.gD[idx].y;
                 keep = cone_keeps(cone, a, bq);
             }
             const unsigned long long mask = __ballot(keep);
             const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            if (keep && pos < PCAP) { s_idx[pos] = idx; s_A[pos] = a; s_B[pos] = bq; }
+            if (keep && pos < PCAP) { s_A[pos] = a; s_B[pos] = bq; s_M[pos] = ms; s_C[pos] = alb; s_q[pos] = q; }
             cnt += (uint32_t)__popcll(mask);
         }
         __syncthreads();
 
+        const unsigned long long tl1 = O.timeline ? wall_clock64() : 0ull;
         // ---- lane cull: this ray's own candidates (exact per-ray criterion x > cull_x, no margin needed) ----
         uint32_t nl = 0;
         bool fast = cnt <= PCAP;
@@ -517,10 +562,7 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
             if (O.stats && lane == 0) { atomicAdd(&O.stats[2], 1ull); atomicAdd(&O.stats[5], 1ull); }
             float Lr, Lg, Lb, La;
             shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La);
-            if (valid) {
-                if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
-                if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
-            }
+            write_block(Lr, Lg, Lb, La, valid, out);
             continue;
         }
         if (O.stats && lane == 0) {
@@ -537,15 +579,26 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((int)tot, off, 64);
             if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); }
         }
+        const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
         float Lr, Lg, Lb, La;
-        shade_lanes<EXP, ERF, EC>(S, s_idx, s_A, s_B, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
-        if (valid) {
-            if (O.image) O.image[out] = pack_pixel(Lr, Lg, Lb, La, O.pack_flags);
-            if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
+        shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+        write_block(Lr, Lg, Lb, La, valid, out);
+        if (O.timeline && lane == 0) {
+            unsigned long long *tl = O.timeline + 5 * (size_t)item;
+            tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
+            const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, 32 bits
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+            tl[4] = ((unsigned long long)xcc << 32) | hw;
         }
     }
 }
 
+// This file is compiled twice (csrc/Makefile): once for everything except the one-wave image kernel, and once with
+// -DVRT_TU_LANES for that kernel alone under -mllvm -amdgpu-sched-strategy=max-ilp.  The default scheduler chains the
+// 20 independent erf terms of an absorber one after the other through two registers to save VGPRs, so a wave that is
+// alone on its SIMD (the tail of the kernel) crawls; max-ilp interleaves them (145 VGPRs, three waves per SIMD, which is
+// what the persistent grid uses anyway).  The 16-wave dense kernel has the thread-level parallelism and keeps the default.
+#ifndef VRT_TU_LANES
 // ---------------------------------------------------------------------------------------------
 // Dense blocks (hundreds of candidates per 8x8 block: sigma of many pixels, rays of a block see the
 // same Gaussians).  One 16-wave workgroup per block: the block's candidates are culled cooperatively
@@ -798,6 +851,9 @@ void launch_order_dense(const CellGrid &c, hipStream_t st)
     hipLaunchKernelGGL(order_dense_kernel, dim3(1), dim3(1024), 0, st, c);
 }
 
+#endif // !VRT_TU_LANES
+
+#ifdef VRT_TU_LANES
 template <int EXP, int ERF>
 static void launch_render_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                             const RenderTarget &o, uint32_t grid, hipStream_t st)
@@ -805,6 +861,8 @@ static void launch_render_t(const SceneTables &s, const TileLists &t, const Cell
     if (grid == 0) return;
     hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
 }
+
+#endif // VRT_TU_LANES
 
 #define VRT_DISPATCH_EXP_ERF(FN, ...)                                                              \
     switch (exp_kind * 8 + erf_kind) {                                                             \
@@ -820,11 +878,13 @@ static void launch_render_t(const SceneTables &s, const TileLists &t, const Cell
     default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
     }
 
+#ifdef VRT_TU_LANES
 void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r, const RenderTarget &o,
                    uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
     VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, st);
 }
+#else
 
 template <int EXP, int ERF>
 static void launch_render_dense_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
@@ -1364,4 +1424,5 @@ void launch_eval_exp(int kind, const float *x, size_t n, float *y, hipStream_t s
     }
 }
 
+#endif // !VRT_TU_LANES
 } // namespace vrtk
