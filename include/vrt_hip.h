@@ -171,7 +171,9 @@ int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 int vrt_hip_enable_stats(vrt_hip_ctx *ctx, int on);
 /* Kernel timing for roofline reports: while enabled, every render launch is bracketed with HIP events ON THE
  * STREAM IT RUNS ON (ring of the last 512 launches).  get() waits for them and returns the mean duration of
- * the one-wave-per-block render kernel, of the 16-waves-per-block (dense) kernel and of the list kernels. */
+ * the one-wave-per-block render kernel, of the 16-waves-per-block (dense) kernel and of the list kernels.
+ * on = 1: four events per frame (all three durations); on = 2: two events, around the one-wave render kernel only
+ * (the other two durations read 0) -- an event costs the stream 2-3 us, which matters for 0.07 ms frames. */
 int vrt_hip_enable_kernel_timing(vrt_hip_ctx *ctx, int on);
 int vrt_hip_get_kernel_timing(vrt_hip_ctx *ctx, double *render_ms, double *dense_ms, double *lists_ms, uint64_t *launches);
 

@@ -74,7 +74,7 @@ struct vrt_hip_ctx {
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
     // second level: 32x32-pixel cells of the local tiles + the active/inactive queues of the render kernel
-    DevBuf<uint32_t> c_count, c_indices, c_active, c_inactive, c_dense, c_dense_sorted, c_overflow, c_counters, c_rq;
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_overflow, c_counters, c_rq;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
     int render_waves_per_cu = 12; // persistent one-wave workgroups per CU (LDS allows 13); VRT_HIP_RENDER_WAVES overrides
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
@@ -119,13 +119,15 @@ struct vrt_hip_ctx {
     DevBuf<uint32_t> d_image;
     DevBuf<float4> d_rad;
     DevBuf<unsigned long long> d_stats, d_timeline; // d_timeline: VRT_HIP_TIMELINE=1 diagnostics
-    size_t timeline_items = 0;
+    size_t timeline_items = 0, timeline_tiles = 0;
+    DevBuf<unsigned long long> d_timeline_lists;
     bool stats_on = false;
     vrt_hip_stats last{};
     // kernel timing ring (vrt_hip_enable_kernel_timing)
     static constexpr int TIMING_RING = 512;
     bool timing_on = false;
     std::vector<hipEvent_t> tev; // 4 per slot: before lists, before render, after render, after dense
+    bool timing_full = true;
     uint64_t timing_count = 0;
 };
 
@@ -304,9 +306,9 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     CellGrid g{};
     uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
     g.cells_x = c->cells_x; g.cells_y = c->cells_y; g.cstride = c->cstride;
-    g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.inactive = c->c_inactive.p;
+    g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.n_cells = c->n_cells;
     g.dense = c->c_dense.p; g.dense_sorted = c->c_dense_sorted.p;
-    g.n_active = cnt; g.n_inactive = cnt + 1; g.n_dense = cnt + 2;
+    g.n_active = cnt; g.n_dense = cnt + 2;
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
@@ -337,7 +339,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     c->n_cells = n_local * c->cells_x * c->cells_y;
     c->cstride = std::max(1u, std::min(c->n, 4096u));
     HIPCHK(c, c->c_count.reserve(c->n_cells)); HIPCHK(c, c->c_active.reserve(c->n_cells));
-    HIPCHK(c, c->c_inactive.reserve(c->n_cells)); HIPCHK(c, c->c_dense.reserve(c->n_cells));
+    HIPCHK(c, c->c_dense.reserve(c->n_cells));
     HIPCHK(c, c->c_dense_sorted.reserve(c->n_cells));
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
@@ -367,6 +369,13 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     f.tile_map = fuse ? tile_map : nullptr;
     f.C = cell_grid(c);
     if (fuse && target) { f.O = *target; f.do_clear = 1; }
+    c->timeline_tiles = 0;
+    if (fuse && getenv("VRT_HIP_TIMELINE")) {
+        c->timeline_tiles = n_local;
+        HIPCHK(c, c->d_timeline_lists.reserve((size_t)n_local * 8));
+        HIPCHK(c, hipMemsetAsync(c->d_timeline_lists.p, 0, (size_t)n_local * 8 * sizeof(unsigned long long), st));
+        f.timeline = c->d_timeline_lists.p;
+    }
     uint32_t *other_set = c->c_counters.p + 8 * ((c->list_gen + 1) & 1);
     a.zero8 = fuse ? nullptr : c->c_counters.p + 8 * (c->list_gen & 1);
     if (device_bin) {
@@ -463,7 +472,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
             for (auto &e : c->tev) HIPCHK(c, hipEventCreate(&e));
         }
         tev = &c->tev[4 * (c->timing_count % vrt_hip_ctx::TIMING_RING)];
-        HIPCHK(c, hipEventRecord(tev[0], st));
+        if (c->timing_full) HIPCHK(c, hipEventRecord(tev[0], st));
     }
     if ((rc = prep_frame(c, origin, st))) return rc;
     RenderTarget o{};
@@ -526,7 +535,10 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         launch_render_dense(tables(c), t, cg, ray_gen(c, origin), o,
                             (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16))),
                             c->dense_waves, c->exp_kind, c->erf_kind, st);
-    if (tev) { HIPCHK(c, hipEventRecord(tev[3], st)); ++c->timing_count; }
+    if (tev) {
+        if (c->timing_full) HIPCHK(c, hipEventRecord(tev[3], st));
+        ++c->timing_count;
+    }
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;
 }
@@ -610,9 +622,9 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
-    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_inactive.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_overflow.release(); c->c_counters.release(); c->c_rq.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_overflow.release(); c->c_counters.release(); c->c_rq.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
-    c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release();
+    c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
     for (auto &e : c->tev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -882,6 +894,37 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
 // VRT_HIP_TIMELINE=1: where the one-wave kernel's time goes (wall_clock64 ticks are 10 ns), printed by vrt_hip_render()
 static void print_timeline(vrt_hip_ctx *c)
 {
+    if (c->timeline_tiles) {
+        std::vector<unsigned long long> tt(c->timeline_tiles * 8);
+        if (hipMemcpy(tt.data(), c->d_timeline_lists.p, tt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long a = ~0ull, b = 0;
+            double ph[5] = {0, 0, 0, 0, 0}, s_start = 0, n = 0, worst = 0, wph[5] = {0, 0, 0, 0, 0};
+            size_t worst_i = 0;
+            for (size_t i = 0; i < c->timeline_tiles; ++i) {
+                const unsigned long long *e = &tt[8 * i];
+                if (!e[4]) continue;
+                a = std::min(a, e[0]); b = std::max(b, e[5] ? e[5] : e[4]);
+            }
+            for (size_t i = 0; i < c->timeline_tiles; ++i) {
+                const unsigned long long *e = &tt[8 * i];
+                if (!e[4]) continue;
+                n += 1; s_start += (double)(e[0] - a);
+                for (int k = 0; k < 5; ++k) ph[k] += (e[k + 1] >= e[k] && e[k + 1]) ? (double)(e[k + 1] - e[k]) : 0.0;
+                const double dur = (double)((e[5] ? e[5] : e[4]) - e[0]);
+                if (dur > worst) {
+                    worst = dur; worst_i = i;
+                    for (int k = 0; k < 5; ++k) wph[k] = (e[k + 1] >= e[k] && e[k + 1]) ? (double)(e[k + 1] - e[k]) : 0.0;
+                }
+            }
+            if (n > 0)
+                fprintf(stderr, "[vrt_hip] list kernel timeline: %.0f tiles, span %.2f us, mean start %.2f us; per tile: cone %.2f us, "
+                                "level 1 %.2f us, level 2 %.2f us, filing %.2f us, clear %.2f us\n", n, (b - a) * 0.01, s_start / n * 0.01,
+                        ph[0] / n * 0.01, ph[1] / n * 0.01, ph[2] / n * 0.01, ph[3] / n * 0.01, ph[4] / n * 0.01);
+            if (n > 0)
+                fprintf(stderr, "[vrt_hip]   slowest tile %zu: %.2f us = %.2f + %.2f + %.2f + %.2f + %.2f\n", worst_i, worst * 0.01,
+                        wph[0] * 0.01, wph[1] * 0.01, wph[2] * 0.01, wph[3] * 0.01, wph[4] * 0.01);
+        }
+    }
     std::vector<unsigned long long> tl(c->timeline_items * 5);
     if (hipMemcpy(tl.data(), c->d_timeline.p, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
     unsigned long long t0 = ~0ull, t1 = 0;
@@ -1077,6 +1120,7 @@ int vrt_hip_enable_kernel_timing(vrt_hip_ctx *c, int on)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     c->timing_on = on != 0;
+    c->timing_full = on != 2; // 2: events around the one-wave render kernel only (two per frame instead of four)
     if (on) c->timing_count = 0;
     return VRT_HIP_OK;
 }
@@ -1089,11 +1133,13 @@ int vrt_hip_get_kernel_timing(vrt_hip_ctx *c, double *render_ms, double *dense_m
     double sr = 0, sd = 0, sl = 0;
     for (uint64_t i = 0; i < n; ++i) {
         hipEvent_t *e = &c->tev[4 * i];
-        HIPCHK(c, hipEventSynchronize(e[3]));
+        HIPCHK(c, hipEventSynchronize(e[c->timing_full ? 3 : 2]));
         float a = 0, b = 0, d = 0;
-        HIPCHK(c, hipEventElapsedTime(&a, e[0], e[1]));
         HIPCHK(c, hipEventElapsedTime(&b, e[1], e[2]));
-        HIPCHK(c, hipEventElapsedTime(&d, e[2], e[3]));
+        if (c->timing_full) {
+            HIPCHK(c, hipEventElapsedTime(&a, e[0], e[1]));
+            HIPCHK(c, hipEventElapsedTime(&d, e[2], e[3]));
+        }
         sl += a; sr += b; sd += d;
     }
     if (render_ms) *render_ms = n ? sr / n : 0.0;

@@ -34,16 +34,17 @@ struct TileLists {
     uint32_t stride;          // tile_w * tiles_w: the reference's row stride, rt.h:364-365
 };
 
-// Second-level (cell) candidate lists and the active / inactive cell queues of the persistent render kernel.
+// Second-level (cell) candidate lists and the cell queues of the render kernels (empty cells: count == 0, no queue).
 struct CellGrid {
     uint32_t cells_x, cells_y;       // cells per tile
     uint32_t cstride;                // capacity of a cell's list slot
     uint32_t *count;                 // [cells]; 0xFFFFFFFF = overflowed its slot: use the tile's list
     uint32_t *indices;               // cell c at indices + c*cstride
-    uint32_t *active, *inactive;     // cell ids: shaded one wavefront per block / only cleared
+    uint32_t n_cells;                // cells of all local tiles
+    uint32_t *active;                // cell ids with short lists: shaded one wavefront per block
     uint32_t *dense;                 // cell ids with long lists: shaded one 16-wave workgroup per block
     uint32_t *dense_sorted;          // the same, longest list first (order_dense_kernel): the queue order of the dense kernel
-    uint32_t *n_active, *n_inactive, *n_dense; // device counters, zeroed before build_cell_lists_kernel
+    uint32_t *n_active, *n_dense;    // device counters, zeroed before the list kernels add to them
     uint32_t *dense_next;            // work counter of the dense kernel (zeroed with the others)
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
                                      // LDS slots: it hands them to the dense kernel, which runs after it
@@ -127,6 +128,7 @@ struct FuseArgs {
     const uint32_t *tile_map;  // local tile -> tile id (nullptr = identity); the grid is over LOCAL tiles
     CellGrid C;
     RenderTarget O;
+    unsigned long long *timeline; // nullable diagnostics: 8 wall_clock64 stamps per tile workgroup
 };
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,

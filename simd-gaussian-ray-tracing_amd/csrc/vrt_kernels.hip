@@ -302,6 +302,18 @@ __device__ __forceinline__ void shade_lanes(const float4 *s_A, const float4 *s_B
 // ---------------------------------------------------------------------------------------------
 // Rays and cones
 // ---------------------------------------------------------------------------------------------
+// (column, row) of raster index pix; 32-bit division whenever the index fits (a 64-bit divide is a ~150-instruction
+// software routine on this hardware)
+__device__ __forceinline__ void col_row(const RayGen &R, uint64_t pix, uint32_t &jcol, uint32_t &irow)
+{
+    if (pix <= 0xFFFFFFFFull) {
+        const uint32_t p = (uint32_t)pix;
+        irow = p / R.width; jcol = p - irow * R.width;
+    } else {
+        irow = (uint32_t)(pix / R.width); jcol = (uint32_t)(pix % R.width);
+    }
+}
+
 // World-space ray through raster pixel `pix` (rt.h:362-371).
 __device__ __forceinline__ LaneRay pixel_ray(const RayGen &R, uint64_t pix)
 {
@@ -310,7 +322,8 @@ __device__ __forceinline__ LaneRay pixel_ray(const RayGen &R, uint64_t pix)
         px = R.xs[pix]; py = R.ys[pix]; pz = R.zs[pix];
     } else {
         // closed form of camera.cpp:52,60-69: plane = pos + x right + y up - focal front
-        const uint32_t jcol = (uint32_t)(pix % R.width), irow = (uint32_t)(pix / R.width);
+        uint32_t jcol, irow;
+        col_row(R, pix, jcol, irow);
         const float x = -1.f + (float)jcol * R.inv_half_w;
         const float y = -1.f + (float)irow * R.inv_half_h;
         px = R.pos[0] + x * R.right[0] + y * R.up[0] - R.focal * R.front[0];
@@ -363,7 +376,8 @@ __device__ __forceinline__ LaneRay cone_ray(const RayGen &R, uint64_t pix)
     if (R.xs) {
         px = R.xs[pix]; py = R.ys[pix]; pz = R.zs[pix];
     } else {
-        const uint32_t jcol = (uint32_t)(pix % R.width), irow = (uint32_t)(pix / R.width);
+        uint32_t jcol, irow;
+        col_row(R, pix, jcol, irow);
         const float x = -1.f + (float)jcol * R.inv_half_w, y = -1.f + (float)irow * R.inv_half_h;
         px = R.pos[0] + x * R.right[0] + y * R.up[0] - R.focal * R.front[0];
         py = R.pos[1] + x * R.right[1] + y * R.up[1] - R.focal * R.front[1];
@@ -431,15 +445,16 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     __shared__ uint8_t s_lane[PL * 64];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x, G = gridDim.x;
     const uint64_t npix = (uint64_t)R.width * R.height;
-    const uint32_t n_inactive = *C.n_inactive, n_active = *C.n_active, n_dense_cells = *C.n_dense;
+    const uint32_t n_active = *C.n_active, n_dense_cells = *C.n_dense;
     if (C.feedback && wave == 0 && lane == 0) C.feedback[0] = n_dense_cells;
     // without a dense kernel behind it this kernel also walks the dense cells (slow path for what does not fit)
     const uint32_t n_shade = (n_active + (C.no_dense ? n_dense_cells : 0u)) * 16u;
 
     // ---- clear the cells nothing can reach (4 B per ray: the only HBM traffic of most of the frame) ----
     const uint32_t zero_px = (O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
-    for (uint32_t item = wave; item < n_inactive && !O.cleared; item += G) { // one whole cell per item: 16 x (2 rows of 32 px)
-        const uint32_t cell = C.inactive[item];
+    // (only when the list kernel of this frame did not do it: unfused lists, or a re-render from unchanged lists)
+    for (uint32_t cell = wave; cell < C.n_cells && !O.cleared; cell += G) { // one whole cell per item: 16 x (2 rows of 32 px)
+        if (C.count[cell] != 0u) continue;
         const uint32_t cpt = C.cells_x * C.cells_y;
         const uint32_t lt = cell / cpt, ci = cell % cpt;
         const uint32_t t = O.tile_map ? O.tile_map[lt] : lt;
@@ -971,12 +986,12 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st)
 // ---------------------------------------------------------------------------------------------
 // With F.enabled the same workgroup goes on to the second level: the tile's surviving candidates stay in LDS
 // (index + the two parameter rows the cone test reads) and each of its 16 waves filters them for the tile's
-// 32x32-pixel cells, files every cell as inactive / active / dense (three atomics per TILE) and clears the
+// 32x32-pixel cells, files every non-empty cell as active or dense (at most two atomics per TILE) and clears the
 // pixels of inactive cells on the spot -- no second kernel, no global round trip, no idle clear phase later.
 template <bool FROM_LIST>
 __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseArgs F)
 {
-    __shared__ uint32_t s_wave_cnt[16];
+    __shared__ uint32_t s_wave_cnt[64];
     __shared__ uint32_t s_idx[TCAP];
     __shared__ float4 s_A[TCAP], s_B[TCAP];
     __shared__ uint32_t s_flag[MAX_FUSED_CELLS], s_inact[MAX_FUSED_CELLS];
@@ -988,19 +1003,8 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
     // adds to them); the unfused pipeline clears them here for the cell kernel that follows
     if (P.zero8 && !F.enabled && lt == 0 && tid < 8) P.zero8[tid] = 0;
     if (P.next_zero8 && lt == 0 && tid < 8) P.next_zero8[tid] = 0;
-
-    // (b) tile cone from the centre and the four corner pixels of the tile (pinhole rays: the
-    // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
-    Cone cone = {};
-    if (P.refine) {
-        const uint64_t npix0 = (uint64_t)P.R.width * P.R.height;
-        auto at = [&](uint32_t x, uint32_t y) {
-            uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
-            if (pix >= npix0) pix = npix0 - 1;
-            return cone_ray(P.R, pix);
-        };
-        cone = rect_cone(at, 0, 0, P.tile_w - 1, P.tile_h - 1, lane);
-    }
+    unsigned long long *tl = (F.timeline && tid == 0) ? F.timeline + 8 * (size_t)lt : nullptr;
+    if (tl) tl[0] = wall_clock64();
 
     float x = 0.f, y = 0.f, ax = 0.f, ay = 0.f;
     uint32_t n_in;
@@ -1016,25 +1020,49 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
     }
     uint32_t *out = P.out_indices + P.out_start[t];
     uint32_t total = 0;
-    for (uint32_t base = 0; base < n_in; base += 1024) {
-        const uint32_t k = base + tid;
-        bool keep = false;
-        uint32_t idx = 0;
-        float4 ga, gb;
-        if (k < n_in) {
-            idx = FROM_LIST ? in_list[k] : k;
-            keep = true;
+    // Four candidates per thread and pass: their rows are requested together (one memory round trip instead of four)
+    // and the order-preserving compaction needs one barrier pair per 4096 candidates.  Order = index order:
+    // (sub-pass u, wave, lane) lexicographic.
+    bool keep[4];
+    uint32_t idx[4];
+    float4 ga[4], gb[4];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = base + u * 1024 + tid;
+            keep[u] = k < n_in;
+            idx[u] = keep[u] ? (FROM_LIST ? in_list[k] : k) : 0u;
+            if (keep[u] && (P.refine || F.enabled)) { ga[u] = P.gA[idx[u]]; gb[u] = P.gB[idx[u]]; }
+        }
+    };
+    fetch(0); // in flight while the cone is set up
+    // (b) tile cone from the centre and the four corner pixels of the tile (pinhole rays: the
+    // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
+    Cone cone = {};
+    if (P.refine) {
+        const uint64_t npix0 = (uint64_t)P.R.width * P.R.height;
+        auto at = [&](uint32_t x, uint32_t y) {
+            uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
+            if (pix >= npix0) pix = npix0 - 1;
+            return cone_ray(P.R, pix);
+        };
+        cone = rect_cone(at, 0, 0, P.tile_w - 1, P.tile_h - 1, lane);
+    }
+
+    if (tl) tl[1] = wall_clock64();
+    for (uint32_t base = 0; base < n_in; base += 4096) {
+        if (base) fetch(base);
+        unsigned long long mask[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
             // The result is (reference tile test) AND (cone test).  The cone test goes first: it is the cheaper
             // one (no divisions) and drops >95 % of the pairs in sparse scenes.
-            if (P.refine || F.enabled) {
-                ga = P.gA[idx]; gb = P.gB[idx];
-                if (P.refine) keep = cone_keeps(cone, ga, gb);
-            }
+            if (keep[u] && P.refine) keep[u] = cone_keeps(cone, ga[u], gb[u]);
             if constexpr (!FROM_LIST) {
-                if (keep) {
+                if (keep[u]) {
 #pragma clang fp contract(off)
-                    keep = false;
-                    const float4 g = P.mu_sig[idx];
+                    keep[u] = false;
+                    const float4 g = P.mu_sig[idx[u]];
                     // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
                     const float vx = (P.V.m[0] * g.x + P.V.m[4] * g.y) + (P.V.m[8] * g.z + P.V.m[12] * 1.f);
                     const float vy = (P.V.m[1] * g.x + P.V.m[5] * g.y) + (P.V.m[9] * g.z + P.V.m[13] * 1.f);
@@ -1044,31 +1072,38 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
                         if (!(sig < 1e-5f)) {                // rt.cpp:41
                             const float dx = fabsf(x - vx / vz), dy = fabsf(y - vy / vz);
                             const float s33 = 3.3f * sig;
-                            keep = (dx <= ax + s33) && (dy <= ay + s33); // rt.cpp:58-59
+                            keep[u] = (dx <= ax + s33) && (dy <= ay + s33); // rt.cpp:58-59
                         }
                     }
                 }
             }
+            mask[u] = __ballot(keep[u]);
+            if (lane == 0) s_wave_cnt[u * 16 + wave] = (uint32_t)__popcll(mask[u]);
         }
-        const unsigned long long mask = __ballot(keep);
-        if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
         __syncthreads();
-        uint32_t before = 0, chunk = 0;
+        // exclusive prefix over the 64 (sub-pass, wave) counts: one count per lane, wave-level scan
+        const uint32_t v = s_wave_cnt[lane];
+        uint32_t incl = v;
 #pragma unroll
-        for (uint32_t wv = 0; wv < 16; ++wv) {
-            const uint32_t c = s_wave_cnt[wv];
-            before += (wv < wave) ? c : 0;
-            chunk += c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= (uint32_t)off) incl += up;
         }
-        if (keep) {
-            const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            out[pos] = idx;
-            if (F.enabled && pos < TCAP) { s_idx[pos] = idx; s_A[pos] = ga; s_B[pos] = gb; }
+        const uint32_t excl = incl - v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t before = (uint32_t)__shfl((int)excl, u * 16 + (int)wave, 64);
+            if (keep[u]) {
+                const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[u], 0));
+                out[pos] = idx[u];
+                if (F.enabled && pos < TCAP) { s_idx[pos] = idx[u]; s_A[pos] = ga[u]; s_B[pos] = gb[u]; }
+            }
         }
-        total += chunk;
+        total += (uint32_t)__shfl((int)incl, 63, 64);
         __syncthreads();
     }
     if (tid == 0) P.out_count[t] = total;
+    if (tl) tl[2] = wall_clock64();
     if (!F.enabled) return;
 
     // ---------------- second level, fused ----------------
@@ -1109,30 +1144,30 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t na = 0, ni = 0, nd = 0;
-        for (uint32_t k = 0; k < cpt; ++k) {
-            na += s_flag[k] == 1u; nd += s_flag[k] == 3u;
-            if (s_flag[k] == 0u) s_inact[ni++] = k;
+    if (tl) tl[3] = wall_clock64();
+    if (wave == 0) { // cpt <= 64: one flag per lane
+        const uint32_t mine = lane < cpt ? s_flag[lane] : 2u;
+        const unsigned long long m_act = __ballot(mine == 1u), m_dense = __ballot(mine == 3u), m_empty = __ballot(mine == 0u);
+        const uint32_t na = (uint32_t)__popcll(m_act), nd = (uint32_t)__popcll(m_dense);
+        // empty cells are not queued (count == 0 says it): most tiles of a sparse frame then add to no counter at all
+        uint32_t base_a = 0, base_d = 0;
+        if (lane == 0) {
+            if (na) base_a = atomicAdd(C.n_active, na);
+            if (nd) base_d = atomicAdd(C.n_dense, nd);
+            s_base[3] = (uint32_t)__popcll(m_empty);
         }
-        s_base[3] = ni;
-        s_base[0] = na ? atomicAdd(C.n_active, na) : 0u;
-        s_base[1] = ni ? atomicAdd(C.n_inactive, ni) : 0u;
-        s_base[2] = nd ? atomicAdd(C.n_dense, nd) : 0u;
+        base_a = (uint32_t)__shfl((int)base_a, 0, 64); base_d = (uint32_t)__shfl((int)base_d, 0, 64);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t cell = lt * cpt + lane;
+        if (mine == 1u) C.active[base_a + (uint32_t)__popcll(m_act & below)] = cell;
+        else if (mine == 3u) C.dense[base_d + (uint32_t)__popcll(m_dense & below)] = cell;
+        else if (mine == 0u) s_inact[(uint32_t)__popcll(m_empty & below)] = lane;
     }
     __syncthreads();
-    if (tid < cpt) {
-        uint32_t before = 0;
-        const uint32_t mine = s_flag[tid];
-        for (uint32_t k = 0; k < tid; ++k) before += s_flag[k] == mine;
-        const uint32_t cell = lt * cpt + tid;
-        if (mine == 1u) C.active[s_base[0] + before] = cell;
-        else if (mine == 3u) C.dense[s_base[2] + before] = cell;
-        else C.inactive[s_base[1] + before] = cell;
-    }
 
     // ---- clear the cells nothing can reach: 4 B per ray, most of the frame's HBM traffic.  All 1024 threads,
     //      16-byte stores (4 pixels per lane, 512 B per row segment) when the geometry is 4-pixel aligned ----
+    if (tl) tl[4] = wall_clock64();
     if (!F.do_clear) return;
     const uint32_t zero_px = (F.O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
     const bool wide = F.O.image && !F.O.radiance && (P.tile_w % 4 == 0) && (P.stride % 4 == 0) &&
@@ -1160,6 +1195,7 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
             }
         }
     }
+    if (tl) tl[5] = wall_clock64();
 }
 
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st)
@@ -1223,10 +1259,9 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
     if (lane == 0) s_flag[wave] = cell < n_cells ? (total ? (total > C.dense_threshold ? 3u : 1u) : 0u) : 2u;
     __syncthreads();
     if (tid == 0) {
-        uint32_t na = 0, ni = 0, nd = 0;
-        for (int w = 0; w < 16; ++w) { na += s_flag[w] == 1u; ni += s_flag[w] == 0u; nd += s_flag[w] == 3u; }
+        uint32_t na = 0, nd = 0;
+        for (int w = 0; w < 16; ++w) { na += s_flag[w] == 1u; nd += s_flag[w] == 3u; }
         s_base[0] = na ? atomicAdd(C.n_active, na) : 0u;
-        s_base[1] = ni ? atomicAdd(C.n_inactive, ni) : 0u;
         s_base[2] = nd ? atomicAdd(C.n_dense, nd) : 0u;
     }
     __syncthreads();
@@ -1236,7 +1271,6 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
         for (uint32_t w = 0; w < wave; ++w) before += s_flag[w] == mine;
         if (mine == 1u) C.active[s_base[0] + before] = cell;
         else if (mine == 3u) C.dense[s_base[2] + before] = cell;
-        else C.inactive[s_base[1] + before] = cell;
     }
 }
 
