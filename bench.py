@@ -272,7 +272,7 @@ def main():
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
         traffic, traffic_frame, valu = None, None, None
         try:    # PMC passes are separate runs (profiles/README.md); their committed summary supplies `traffic`
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
             if world == 1 and args.grid == 64 and w == 2048 and not args.plane_arrays:
                 traffic = pmc["render_kernel_traffic_bytes_per_launch"]["lower"]
                 traffic_frame = pmc["frame_hbm_bytes"]["write"] + pmc["frame_hbm_bytes"]["fetch_raw"]
@@ -280,7 +280,7 @@ def main():
                 if nv:
                     rate = nv / (kernel_ms * 1e-3)
                     valu = {"wave_instructions_per_launch": nv, "achieved_per_s": rate, "peak_per_s": VALU_PEAK_WAVE_INSTR,
-                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01b_pmc_traffic.json (SQ_INSTS_VALU)"}
+                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01c_pmc_traffic.json (SQ_INSTS_VALU)"}
         except (OSError, KeyError, ValueError):
             pass
         result = {
@@ -295,6 +295,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": render_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": render_bytes,
+                         # an event pair with nothing between reads ~4.6 us on this stack: rocprofv3's kernel duration
+                         # (profiles/) is the event figure minus that.  `achieved` uses the raw (larger) event figure.
+                         "event_pair_overhead_ms": kt["dense_ms"] if st["dense_blocks"] == 0 else None,
                          "launch_sequence_ms": {"lists": kt["lists_ms"], "render_kernel": kt["render_ms"],
                                                 "render_dense_kernel": kt["dense_ms"]},
                          "frame": {"algorithmic_bytes": frame_bytes, "ms": frame_ms, "achieved": frame_gbs,
