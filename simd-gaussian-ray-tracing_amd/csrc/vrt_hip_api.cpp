@@ -501,7 +501,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     const uint32_t bx = (t.tile_w + BLOCK_W - 1) / BLOCK_W, by = (t.tile_h + BLOCK_H - 1) / BLOCK_H;
     c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
-    // persistent grid: 16 wavefronts per CU (LDS- and VGPR-limited residency), never more than there are blocks
+    // persistent grid: 12 one-wave workgroups per CU (three per SIMD at 145 VGPRs), never more than there are blocks
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * c->render_waves_per_cu);
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
         HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1) + 3, 0, 2 * sizeof(uint32_t), st));
@@ -523,7 +523,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         HIPCHK(c, c->c_rq.reserve(2 * RQ_N * RQ_STRIDE));
         HIPCHK(c, hipMemsetAsync(c->c_rq.p, 0, 2 * RQ_N * RQ_STRIDE * sizeof(uint32_t), st));
     }
-    ++c->rq_gen;
+    if (grid) ++c->rq_gen; // a skipped launch clears nothing: the sets must not swap
     cg.rq = c->c_rq.p + (c->rq_gen & 1) * RQ_N * RQ_STRIDE;
     cg.rq_next = c->c_rq.p + ((c->rq_gen + 1) & 1) * RQ_N * RQ_STRIDE;
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
