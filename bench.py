@@ -147,70 +147,31 @@ def main():
     torch.cuda.synchronize()
 
     image = torch.zeros(w * h, dtype=torch.int32, device="cuda")
-    # N > 1: every rank renders its tile shard of F consecutive frames into one buffer and the shards travel to rank 0
-    # in ONE gather per F frames ([rank][frame][shard] on rank 0) - fewer, larger collectives: a 2048^2 frame is
-    # ~0.08 ms of GPU work, less than the launch + handshake cost of one RCCL call.  Two buffers: the gather of
-    # batch i overlaps the rendering of batch i + 1.  Rank 0 assembles every gathered frame into raster order.
-    F = max(1, min(args.gather_frames, max(args.steps, 1)))
-    if world > 1:
-        npx = r.shard_pixels()
-        shard = [torch.zeros(F * npx, dtype=torch.int32, device="cuda") for _ in range(2)]
-        gathered = [torch.zeros(world * F * npx, dtype=torch.int32, device="cuda") if rank == 0 else None for _ in range(2)]
-        _views = {}
-
-    def views(b, nf):
-        if (b, nf) not in _views:
-            dst = [gathered[b][q * F * npx: q * F * npx + nf * npx] for q in range(world)] if rank == 0 else None
-            _views[(b, nf)] = (shard[b][: nf * npx], dst)
-        return _views[(b, nf)]
-
-    class _Done:
-        def wait(self):
-            return None
-
-    def gather_async(b, nf):
-        src, dst = views(b, nf)
-        if backend == "nccl":
-            return dist.gather(src, dst, dst=0, async_op=True)
-        torch.cuda.synchronize()                      # rehearsal path: stage through the host
-        host = src.cpu()
-        out = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-        dist.gather(host, out, dst=0)
-        if rank == 0:
-            for q in range(world):
-                dst[q].copy_(out[q])
-        return _Done()
-
     frame = r.frame_call(tw, th, view, origin, pack, shard=world > 1)   # tile_gaussians + render, one C call
     img_ptr = image.data_ptr()
-    shard_ptr = [s_.data_ptr() for s_ in shard] if world > 1 else None
+    # N > 1: sharding.FrameGatherer -- every rank renders its tile shard of F consecutive frames into one buffer, ONE
+    # gather per F frames moves them to rank 0 (double-buffered against the next batch's rendering), rank 0 assembles
+    # every gathered frame into raster order.  The same class runs under gloo in tests/test_dist_gloo.py.
+    F = max(1, min(args.gather_frames, max(args.steps, 1)))
+    if world > 1:
+        from sgrt_amd.sharding import FrameGatherer
+        npx = r.shard_pixels()
+        fg = FrameGatherer(dist, rank, world, npx, F, "cuda", stage=backend != "nccl")
+        shard_ptr = [t_.data_ptr() for t_ in fg.shard]
+        gath_ptr = [t_.data_ptr() if t_ is not None else 0 for t_ in fg.gathered]
+
+        def render_shard(b, f):
+            frame(shard_ptr[b] + 4 * f * npx, sp)
+
+        def assemble(b, f):
+            r.assemble_shards_device(gath_ptr[b] + 4 * f * npx, img_ptr, sp, rank_stride_px=F * npx)
 
     def run(nsteps):
         if world == 1:
             for _ in range(nsteps):
                 frame(img_ptr, sp)
-            return
-        pending, nfs = [None, None], [0, 0]
-
-        def finish(b):
-            pending[b].wait()
-            if rank == 0:
-                for f in range(nfs[b]):
-                    r.assemble_shards_device(gathered[b].data_ptr() + 4 * f * npx, img_ptr, sp, rank_stride_px=F * npx)
-            pending[b] = None
-
-        for i in range((nsteps + F - 1) // F):
-            b, nf = i & 1, min(F, nsteps - i * F)
-            if pending[b] is not None:
-                finish(b)
-            for f in range(nf):
-                frame(shard_ptr[b] + 4 * f * npx, sp)
-            nfs[b], pending[b] = nf, gather_async(b, nf)
-            if pending[1 - b] is not None:
-                finish(1 - b)
-        for b in (0, 1):
-            if pending[b] is not None:
-                finish(b)
+        else:
+            fg.run(nsteps, render_shard, assemble)
 
     def barrier():
         if world > 1:

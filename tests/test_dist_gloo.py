@@ -1,10 +1,12 @@
-"""Multi-process (world_size 2 and 3, gloo, CPU) test of the N > 1 path: tile shards -> gather -> assemble.
+"""Multi-process (world_size 2, 3 and 8, gloo, CPU) test of the N > 1 path: tile shards -> gather -> assemble.
 
 The shard map and buffer layout are the ones csrc/vrt_hip_api.cpp uses on the GPUs (mirrored on the
 host in sharding.py; their equality with the device code is checked on the GPU by
 test_gpu_parity.py::test_sharded_render_assembles_to_full_frame).  Here every rank produces its shard
 of a small frame with the CPU oracle standing in for the HIP render, the shards travel through the same
 torch.distributed gather bench.py issues over RCCL, and rank 0 must end up with the single-process frame.
+The second test drives sharding.FrameGatherer -- the batched, double-buffered frame loop bench.py runs for N > 1 --
+with frames that differ from one another, so that a frame assembled from the wrong batch slot would show.
 """
 import os
 import socket
@@ -75,3 +77,49 @@ def test_tile_sharded_gather_reproduces_the_frame(world, tmp_path, oracle, pkg):
     full, _ = oracle.render(w, h, cam.plane(), cam.position, g, tiles, threads=2)
     np.testing.assert_array_equal(frame, full.reshape(h, w))
     assert (frame >> 24).max() > 0
+
+
+def _loop_worker(rank, world, port, out_path, nsteps, frames_per_gather):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    load_pkg()
+    from sgrt_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tiles_n, tile_w, tile_h = 4, 8, 4
+        h, w = tiles_n * tile_h, tiles_n * tile_w
+        tab = sharding.shard_table(tiles_n, tiles_n, world)
+        base = (np.arange(h * w, dtype=np.uint32) * 2654435761 & 0x7FFFFFFF).reshape(h, w)   # frame k = base + k
+        npx = tab.shape[1] * tile_w * tile_h
+        fg = sharding.FrameGatherer(dist, rank, world, npx, frames_per_gather, "cpu")
+        which, counter, frames = {}, [0], []
+
+        def render(b, f):
+            k = counter[0]; counter[0] += 1
+            which[(b, f)] = k
+            shard = sharding.extract_shard(base + np.uint32(k), tab, rank, tiles_n, tile_w, tile_h)
+            fg.shard_frame(b, f).copy_(torch.from_numpy(shard.view(np.int32).ravel()))
+
+        def assemble(b, f):
+            view, stride = fg.gathered_frame(b, f)
+            parts = np.stack([view[q * stride: q * stride + npx].numpy() for q in range(world)]).view(np.uint32)
+            frames.append((which[(b, f)], sharding.assemble(parts, tab, tiles_n, tile_w, tile_h, h, w)))
+
+        fg.run(nsteps, render, assemble)
+        if rank == 0:
+            assert [k for k, _ in frames] == list(range(nsteps))           # every frame, in order
+            for k, fr in frames:
+                np.testing.assert_array_equal(fr, base + np.uint32(k))
+            np.save(out_path, np.array([len(frames)]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nsteps,frames_per_gather", [(2, 7, 3), (3, 4, 4), (8, 5, 2), (2, 3, 1)])
+def test_batched_frame_loop(world, nsteps, frames_per_gather, tmp_path, pkg):
+    out = str(tmp_path / "n.npy")
+    mp.spawn(_loop_worker, args=(world, _free_port(), out, nsteps, frames_per_gather), nprocs=world, join=True)
+    assert int(np.load(out)[0]) == nsteps
