@@ -173,7 +173,8 @@ int vrt_hip_enable_stats(vrt_hip_ctx *ctx, int on);
  * STREAM IT RUNS ON (ring of the last 512 launches).  get() waits for them and returns the mean duration of
  * the one-wave-per-block render kernel, of the 16-waves-per-block (dense) kernel and of the list kernels.
  * on = 1: four events per frame (all three durations); on = 2: two events, around the one-wave render kernel only
- * (the other two durations read 0) -- an event costs the stream 2-3 us, which matters for 0.07 ms frames. */
+ * (the other two durations read 0) -- an event costs the stream 2-3 us, which matters for 0.06 ms frames;
+ * on = 3: like 2, on every 8th frame only. */
 int vrt_hip_enable_kernel_timing(vrt_hip_ctx *ctx, int on);
 int vrt_hip_get_kernel_timing(vrt_hip_ctx *ctx, double *render_ms, double *dense_ms, double *lists_ms, uint64_t *launches);
 

@@ -128,6 +128,7 @@ struct vrt_hip_ctx {
     bool timing_on = false;
     std::vector<hipEvent_t> tev; // 4 per slot: before lists, before render, after render, after dense
     bool timing_full = true;
+    uint32_t timing_period = 1, timing_frame = 0;
     uint64_t timing_count = 0;
 };
 
@@ -466,7 +467,8 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (geo.tile_w == 0 || geo.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
     const bool use_shard = c->world > 1 || shard_compact;
     hipEvent_t *tev = nullptr;
-    if (c->timing_on) {
+    const bool timed_frame = c->timing_on && (c->timing_frame++ % c->timing_period) == 0;
+    if (timed_frame) {
         if (c->tev.empty()) {
             c->tev.resize(4 * vrt_hip_ctx::TIMING_RING);
             for (auto &e : c->tev) HIPCHK(c, hipEventCreate(&e));
@@ -1120,8 +1122,9 @@ int vrt_hip_enable_kernel_timing(vrt_hip_ctx *c, int on)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     c->timing_on = on != 0;
-    c->timing_full = on != 2; // 2: events around the one-wave render kernel only (two per frame instead of four)
-    if (on) c->timing_count = 0;
+    c->timing_full = on == 1; // 2, 3: events around the one-wave render kernel only (two per frame instead of four)
+    c->timing_period = on == 3 ? 8 : 1; // 3: on every 8th frame only
+    if (on) { c->timing_count = 0; c->timing_frame = 0; }
     return VRT_HIP_OK;
 }
 
