@@ -73,7 +73,7 @@ struct vrt_hip_ctx {
     DevBuf<uint32_t> ref_start, ref_count, ref_indices;
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
-    // second level: 32x32-pixel cells of the local tiles + the active/inactive queues of the render kernel
+    // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_overflow, c_counters, c_rq;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
     int render_waves_per_cu = 12; // persistent one-wave workgroups per CU (LDS allows 13); VRT_HIP_RENDER_WAVES overrides

@@ -79,7 +79,7 @@ struct RenderTarget {
     const uint32_t *tile_map;
     uint32_t n_local_tiles;
     int compact;
-    int cleared;              // inactive cells were already cleared by the list kernel of this frame
+    int cleared;              // empty cells were already cleared by the list kernel of this frame
     unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
                                // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
     unsigned long long *timeline; // nullable diagnostics: 4 wall_clock64 stamps + the hardware id per one-wave work item (5 words)

@@ -414,10 +414,10 @@ __device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/
 }
 
 // ---------------------------------------------------------------------------------------------
-// Image kernel: persistent wavefronts; a work item is one 8x8 pixel block (64 rays, lane = ray) of a
-// 32x32 pixel cell.  Cells whose candidate list is empty are only cleared; the others are shaded.
-// Items are dealt to waves round-robin (item = wave + k*gridDim): no queue, no atomics, every wave's
-// loop bound comes from the two cell counters the list kernels left in memory.
+// Image kernel: persistent one-wave workgroups; a work item is one 8x8 pixel block (64 rays, lane = ray) of a
+// 32x32 pixel cell with a non-empty candidate list.  A wave's first block is static (item = wave); frames with
+// more blocks than waves hand the rest out through eight work counters (CellGrid::rq).  Empty cells are cleared
+// by the fused list kernel; when that did not run for this target (unfused lists, re-render) they are cleared here.
 // ---------------------------------------------------------------------------------------------
 struct BlockPos { uint32_t lt, t, pxt, pyt; bool inside; };
 __device__ __forceinline__ BlockPos block_of(const TileLists &T, const CellGrid &C, const RenderTarget &O, uint32_t cell,
@@ -987,7 +987,7 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st)
 // With F.enabled the same workgroup goes on to the second level: the tile's surviving candidates stay in LDS
 // (index + the two parameter rows the cone test reads) and each of its 16 waves filters them for the tile's
 // 32x32-pixel cells, files every non-empty cell as active or dense (at most two atomics per TILE) and clears the
-// pixels of inactive cells on the spot -- no second kernel, no global round trip, no idle clear phase later.
+// pixels of empty cells on the spot -- no second kernel, no global round trip, no idle clear phase later.
 template <bool FROM_LIST>
 __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseArgs F)
 {
@@ -1207,14 +1207,14 @@ void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list
 
 // ---------------------------------------------------------------------------------------------
 // Second level: one wavefront per 32x32 pixel cell filters its tile's list with the cell's cone.
-// 16 cells share a 1024-thread workgroup so that filing the cells as active (non-empty list) or
-// inactive (to be cleared) costs two atomics per 16 cells -- one hot counter word serialises at
-// ~11 ns per returning atomic, which 4096 single-cell atomics would turn into the longest kernel.
+// 16 cells share a 1024-thread workgroup so that filing the non-empty cells as active or dense costs
+// at most two atomics per 16 cells -- one hot counter word serialises at ~11 ns per returning atomic,
+// which 4096 single-cell atomics would turn into the longest kernel.  Empty cells: count == 0, no queue.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
                                                                  const uint32_t *tile_map, uint32_t n_cells, int refine)
 {
-    __shared__ uint32_t s_flag[16];  // 0 = inactive, 1 = active (sparse), 3 = active (dense), 2 = no such cell
+    __shared__ uint32_t s_flag[16];  // 0 = empty, 1 = active (sparse), 3 = active (dense), 2 = no such cell
     __shared__ uint32_t s_base[3];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cell = blockIdx.x * 16 + wave;
