@@ -491,3 +491,45 @@ def test_img_error_experiment(pkg, oracle, renderer):
         assert mse_o < 1e-3      # the approximations are image-level accurate (the thesis's conclusion)
     renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
     renderer.clear_tiles()
+
+
+def test_work_queues_and_scheduling_do_not_change_the_image(pkg, oracle, renderer, monkeypatch):
+    """The one-wave kernel hands blocks beyond its grid size out through work counters; which wave shades a block must
+    not show.  One persistent wave per CU (256 waves for 1024 shaded blocks: three quarters of them come from the queues)
+    against the default grid, repeated so that both counter sets are used; bit-identical images and radiances."""
+    w = h = 1024
+    g = oracle.grid_scene(16)
+    cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h)
+    ref_img, ref_rad = renderer.render(origin)
+    assert (ref_img >> 24).max() > 0
+    monkeypatch.setenv("VRT_HIP_RENDER_WAVES", "1")
+    r1 = pkg.Renderer(0)
+    try:
+        setup_scene(pkg, oracle, r1, g, w, h)
+        for _ in range(3):
+            img, rad = r1.render(origin)
+            np.testing.assert_array_equal(img, ref_img)
+            np.testing.assert_array_equal(rad, ref_rad)
+    finally:
+        r1.close()
+
+
+def test_kernel_timing_modes(pkg, oracle, renderer):
+    """vrt_hip_enable_kernel_timing: 1 = four events per frame, 2 = the one-wave kernel only, 3 = that on every 8th frame."""
+    import torch
+    w = h = 256
+    g = oracle.grid_scene(8)
+    cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h)
+    out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    frame = renderer.frame_call(2 / 16, 2 / 16, oracle.camera_view(cam), origin, pkg.PACK_ROUND | pkg.ALPHA_COMPUTED)
+    for mode, launches, full in [(1, 16, True), (2, 16, False), (3, 2, False)]:
+        renderer.enable_kernel_timing(mode)
+        for _ in range(16):
+            frame(out.data_ptr(), st)
+        torch.cuda.synchronize()
+        kt = renderer.kernel_timing()
+        assert kt["launches"] == launches, (mode, kt)
+        assert 0 < kt["render_ms"] < 5.0
+        assert (kt["lists_ms"] > 0) == full and (kt["dense_ms"] > 0) == full, (mode, kt)
+    renderer.enable_kernel_timing(False)
