@@ -952,6 +952,16 @@ static void print_timeline(vrt_hip_ctx *c)
         ++starts[(size_t)((e[0] - t0) * 64.0 / span)]; ++ends[(size_t)((e[3] - t0) * 64.0 / span)];
     }
     if (n == 0) return;
+    if (const char *path = getenv("VRT_HIP_TIMELINE"); path && strstr(path, ".csv")) { // raw stamps for offline analysis
+        if (FILE *f = fopen(path, "w")) {
+            fprintf(f, "item,t0,t1,t2,t3,hw_id,xcc_id,nmax\n");
+            for (size_t i = 0; i < c->timeline_items; ++i) {
+                const unsigned long long *e = &tl[5 * i];
+                if (e[3]) fprintf(f, "%zu,%llu,%llu,%llu,%llu,%u,%u,%u\n", i, e[0] - t0, e[1] - t0, e[2] - t0, e[3] - t0, (unsigned)e[4], (unsigned)(e[4] >> 32) & 0xFFFFu, (unsigned)(e[4] >> 48));
+            }
+            fclose(f);
+        }
+    }
     fprintf(stderr, "[vrt_hip] one-wave kernel timeline: %.0f blocks, span %.2f us, mean start %.2f us, mean end %.2f us; per block: "
                     "block cull %.2f us, lane lists %.2f us, shade+store %.2f us\n[vrt_hip]   running blocks per 1/64 of the span:",
             n, (t1 - t0) * 0.01, s_start / n * 0.01, s_end / n * 0.01, p0 / n * 0.01, p1 / n * 0.01, p2 / n * 0.01);

@@ -503,7 +503,8 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
         const unsigned long long tl0 = O.timeline ? wall_clock64() : 0ull; // diagnostics (VRT_HIP_TIMELINE runs only)
         const uint32_t ci = item >> 4;
         const uint32_t cell = ci < n_active ? C.active[ci] : C.dense[ci - n_active];
-        const BlockPos p = block_of(T, C, O, cell, item & 15u, lane);
+        const uint32_t bi = item & 15u;
+        const BlockPos p = block_of(T, C, O, cell, bi, lane);
         if (!p.inside) continue;
         const uint32_t tx = p.t % T.tiles_w, ty = p.t / T.tiles_w;
         bool valid = p.pxt < T.tile_w && p.pyt < T.tile_h;
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
         }
         __syncthreads();
         if (!fast && !C.no_dense) { // hand the block to the 16-waves-per-block kernel that runs after this one
-            if (lane == 0) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | (item & 15u);
+            if (lane == 0) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | bi;
             continue;
         }
         if (!fast) { // nobody to hand it to: stream the list through scalar loads (any length, one wave)
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
             tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
             const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, 32 bits
             const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
-            tl[4] = ((unsigned long long)xcc << 32) | hw;
+            tl[4] = ((unsigned long long)nmax << 48) | ((unsigned long long)(xcc & 0xFFFFu) << 32) | hw;
         }
     }
 }
