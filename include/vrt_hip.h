@@ -121,6 +121,14 @@ int vrt_hip_render_device(vrt_hip_ctx *ctx, const float origin[3], int pack_flag
 int vrt_hip_frame_device(vrt_hip_ctx *ctx, float tw, float th, const float view[16], const float origin[3],
                          int pack_flags, uint32_t *d_out, int shard, void *hip_stream);
 
+/* The same for callers without device memory of their own (the CLI): the frame goes to the context's own image
+ * buffer on the context's stream.  image_out != NULL: copied out and waited for (a frame whose PNG is written);
+ * image_out == NULL && !wait: returns as soon as the frame is enqueued -- an animation that only reports its
+ * average frame time (main.cpp:310-315) keeps the GPU busy back to back; vrt_hip_sync() waits for the stream. */
+int vrt_hip_frame(vrt_hip_ctx *ctx, float tw, float th, const float view[16], const float origin[3], int pack_flags,
+                  uint32_t *image_out, int wait);
+int vrt_hip_sync(vrt_hip_ctx *ctx);
+
 /* Multi-GPU tile sharding: the context renders only tiles t with shard_of(t) == rank.
  * Owned tiles are written tile-major into a compact buffer of
  * vrt_hip_shard_pixels() u32s: [local tile][tile_h][tile_w].  assemble() scatters the
@@ -165,6 +173,8 @@ typedef struct {
     uint64_t shaded_blocks;  /* blocks that reached the shading loops (the rest were only cleared)    */
     uint64_t dense_blocks;   /* of those, blocks shaded by the 16-waves-per-block kernel              */
     double dense_busy_frac;  /* mean share of that kernel's duration its workgroups had blocks to work on */
+    uint64_t slow_path_total;/* running count (since create) of blocks the one-wave kernel had to shade through its
+                                one-wave-streams-the-whole-list fallback because no dense kernel was launched behind it */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

@@ -34,7 +34,7 @@ class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("tiling_ms", C.c_double), ("rays", C.c_uint64), ("blocks", C.c_uint64),
                 ("list_entries", C.c_uint64), ("tile_entries", C.c_uint64), ("overflow_blocks", C.c_uint64),
                 ("lane_entries", C.c_uint64), ("lane_max_entries", C.c_uint64), ("shaded_blocks", C.c_uint64), ("dense_blocks", C.c_uint64),
-                ("dense_busy_frac", C.c_double)]
+                ("dense_busy_frac", C.c_double), ("slow_path_total", C.c_uint64)]
 
 
 def build(verbose=False):
@@ -68,6 +68,8 @@ SYMBOLS = {
     "vrt_hip_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
     "vrt_hip_shard_pixels": (C.c_size_t, [_vp]),
     "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
+    "vrt_hip_frame": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, C.c_int]),
+    "vrt_hip_sync": (C.c_int, [_vp]),
     "vrt_hip_assemble_shards_device": (C.c_int, [_vp, _vp, _vp, _vp]),
     "vrt_hip_assemble_shards_strided_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "vrt_hip_transmittance": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, _f32p]),

@@ -87,7 +87,9 @@ struct vrt_hip_ctx {
     bool fb_valid = false;        // at least one frame of the current scene/options has reported
     bool dense_launched_last = true;
     uint32_t fb1_seen = 0;
-    uint64_t frames_since_reset = 0;
+    // dense-launch prediction: frame_seq counts render launches; a report in h_fb[3] (the sequence number of the frame
+    // that wrote it) newer than reset_seq comes from the current scene / camera / options
+    uint32_t frame_seq = 0, reset_seq = 0;
     int num_cus = 256;
     int dense_waves = 16; // waves per block in the dense kernel (tuning knob: VRT_HIP_DENSE_WAVES = 4 | 8 | 16)
     bool work_is_ref = false; // render straight from the ref lists (no tile-level cull possible)
@@ -193,6 +195,7 @@ int prep_frame(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
     launch_prep_frame(tables(c), c->gA.p, origin, st);
     HIPCHK(c, hipGetLastError());
     memcpy(c->gA_origin, origin, 3 * sizeof(float));
+    c->reset_seq = c->frame_seq;
     c->gA_valid = true;
     c->lists_dirty = true; // the tile-level cull depends on the origin
     return VRT_HIP_OK;
@@ -512,15 +515,17 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     // cells / slow-path blocks they had; a few frames after the last change of scene or options the report of
     // earlier frames predicts this one.  A wrong "no" costs speed only: the one-wave kernel then shades all itself.
     bool launch_dense = true;
-    if (c->h_fb && c->frames_since_reset >= 8 && !c->stats_on) {
+    // (the report must come from a frame at least two launches after the last change: the host may be many frames
+    // ahead of the GPU, and a report of an older scene or camera must not switch the dense kernel off)
+    if (c->h_fb && !c->stats_on && (int32_t)(c->h_fb[3] - c->reset_seq) >= 2) {
         const uint32_t fb0 = c->h_fb[0], fb1 = c->h_fb[1], fb2 = c->h_fb[2];
         launch_dense = fb0 > 0 || (c->dense_launched_last ? fb2 > 0 : fb1 != c->fb1_seen);
         c->fb1_seen = fb1;
     }
-    ++c->frames_since_reset;
     c->dense_launched_last = launch_dense;
     CellGrid cg = cell_grid(c);
     cg.no_dense = launch_dense ? 0 : 1;
+    cg.frame_seq = ++c->frame_seq;
     if (!c->c_rq.p) {
         HIPCHK(c, c->c_rq.reserve(2 * RQ_N * RQ_STRIDE));
         HIPCHK(c, hipMemsetAsync(c->c_rq.p, 0, 2 * RQ_N * RQ_STRIDE * sizeof(uint32_t), st));
@@ -654,7 +659,7 @@ int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const flo
     }
     c->has_alpha = aa != nullptr;
     c->n = (uint32_t)n;
-    c->frames_since_reset = 0;
+    c->reset_seq = c->frame_seq;
     c->tables_dirty = true;
     c->lists_dirty = true;
     if (c->tile_mode != TILES_HOST) c->ref_valid = false;
@@ -688,7 +693,7 @@ int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_e
                            (exp_kind == VRT_EXP_LIBM && erf_kind == VRT_ERF_LIBM);
     if (!supported) return fail(c, VRT_HIP_ERR_INVALID, "set_options: this Exp/Erf pair is not instantiated");
     if (exp_kind != c->exp_kind || cull_eps != c->cull_eps) c->tables_dirty = true;
-    if (exp_kind != c->exp_kind || erf_kind != c->erf_kind || cull_eps != c->cull_eps) c->frames_since_reset = 0;
+    if (exp_kind != c->exp_kind || erf_kind != c->erf_kind || cull_eps != c->cull_eps) c->reset_seq = c->frame_seq;
     c->exp_kind = exp_kind; c->erf_kind = erf_kind; c->cull_eps = cull_eps;
     return VRT_HIP_OK;
 }
@@ -696,7 +701,7 @@ int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_e
 int vrt_hip_clear_tiles(vrt_hip_ctx *c)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
-    if (c->tile_mode != TILES_NONE) c->frames_since_reset = 0;
+    if (c->tile_mode != TILES_NONE) c->reset_seq = c->frame_seq;
     c->tile_mode = TILES_NONE; c->tw = c->th = 2.f; c->tiles_w = c->tiles_h = 1;
     c->shard_dirty = true; c->lists_dirty = true; c->ref_valid = false;
     return VRT_HIP_OK;
@@ -726,7 +731,7 @@ int vrt_hip_set_tiles(vrt_hip_ctx *c, float tw, float th, uint64_t tiles_w, uint
     HIPCHK(c, hipMemcpy(c->ref_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->ref_count.p, count.data(), nt * 4, hipMemcpyHostToDevice));
     if (total) HIPCHK(c, hipMemcpy(c->ref_indices.p, indices, total * 4, hipMemcpyHostToDevice));
-    c->frames_since_reset = 0;
+    c->reset_seq = c->frame_seq;
     c->tile_mode = TILES_HOST; c->tw = tw; c->th = th; c->tiles_w = (uint32_t)tiles_w; c->tiles_h = (uint32_t)tiles_h;
     c->shard_dirty = true; c->lists_dirty = true; c->ref_valid = true;
     return VRT_HIP_OK;
@@ -744,6 +749,7 @@ int vrt_hip_tile_gaussians_device(vrt_hip_ctx *c, float tw, float th, const floa
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if ((rc = prepare_tile_grid(c, tw, th))) return rc;
     }
+    if (memcmp(c->view, view, 16 * sizeof(float))) c->reset_seq = c->frame_seq;
     memcpy(c->view, view, 16 * sizeof(float));
     c->lists_dirty = true;
     c->ref_valid = false;
@@ -825,7 +831,7 @@ int vrt_hip_set_plane(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float *xs, c
     HIPCHK(c, hipMemcpy(c->ys.p, ys, n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->zs.p, zs, n * 4, hipMemcpyHostToDevice));
     c->plane_affine = plane_is_affine(w, h, xs, ys, zs);
-    if (c->w != w || c->h != h || !c->plane_mode) c->frames_since_reset = 0;
+    c->reset_seq = c->frame_seq; // new rays
     c->w = w; c->h = h; c->plane_mode = true; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
@@ -835,8 +841,10 @@ int vrt_hip_set_camera(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float pos[3
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     if (!w || !h || !pos || !right || !up || !front) return fail(c, VRT_HIP_ERR_INVALID, "set_camera: bad argument");
+    if (c->w != w || c->h != h || c->plane_mode || c->focal != focal || memcmp(c->cam_pos, pos, 12) || memcmp(c->cam_right, right, 12) ||
+        memcmp(c->cam_up, up, 12) || memcmp(c->cam_front, front, 12))
+        c->reset_seq = c->frame_seq; // another camera: earlier frames' reports say nothing about the next one
     memcpy(c->cam_pos, pos, 12); memcpy(c->cam_right, right, 12); memcpy(c->cam_up, up, 12); memcpy(c->cam_front, front, 12);
-    if (c->w != w || c->h != h || c->plane_mode) c->frames_since_reset = 0;
     c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
@@ -855,6 +863,32 @@ int vrt_hip_frame_device(vrt_hip_ctx *c, float tw, float th, const float view[16
     int rc = vrt_hip_tile_gaussians_device(c, tw, th, view, hip_stream);
     if (rc) return rc;
     return render_common(c, origin, pack_flags, d_out, nullptr, (hipStream_t)hip_stream, shard != 0);
+}
+
+int vrt_hip_frame(vrt_hip_ctx *c, float tw, float th, const float view[16], const float origin[3], int pack_flags,
+                  uint32_t *image_out, int wait)
+{
+    if (!c || !origin || !view) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_ready(c);
+    if (rc) return rc;
+    const size_t npix = (size_t)c->w * c->h;
+    if (c->d_image.cap < npix) { // first frame at this size: pixels no tile covers read 0
+        HIPCHK(c, c->d_image.reserve(npix));
+        HIPCHK(c, hipMemsetAsync(c->d_image.p, 0, npix * 4, c->stream));
+    }
+    if ((rc = vrt_hip_frame_device(c, tw, th, view, origin, pack_flags, c->d_image.p, 0, c->stream))) return rc;
+    if (image_out) HIPCHK(c, hipMemcpyAsync(image_out, c->d_image.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    if (image_out || wait) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_sync(vrt_hip_ctx *c)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VRT_HIP_OK;
 }
 
 int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *image_out, float *radiance_out)
@@ -983,7 +1017,7 @@ int vrt_hip_set_shard(vrt_hip_ctx *c, int rank, int world)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     if (world < 1 || rank < 0 || rank >= world) return fail(c, VRT_HIP_ERR_INVALID, "set_shard: bad rank/world");
-    c->rank = rank; c->world = world; c->shard_dirty = true; c->lists_dirty = true; c->frames_since_reset = 0;
+    c->rank = rank; c->world = world; c->shard_dirty = true; c->lists_dirty = true; c->reset_seq = c->frame_seq;
     return VRT_HIP_OK;
 }
 
@@ -1165,6 +1199,7 @@ int vrt_hip_get_kernel_timing(vrt_hip_ctx *c, double *render_ms, double *dense_m
 int vrt_hip_get_stats(vrt_hip_ctx *c, vrt_hip_stats *out)
 {
     if (!c || !out) return VRT_HIP_ERR_INVALID;
+    c->last.slow_path_total = c->h_fb ? c->h_fb[1] : 0;
     *out = c->last;
     return VRT_HIP_OK;
 }

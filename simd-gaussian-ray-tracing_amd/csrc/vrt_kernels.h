@@ -50,10 +50,12 @@ struct CellGrid {
                                      // LDS slots: it hands them to the dense kernel, which runs after it
     uint32_t dense_threshold;        // a cell whose list is longer than this goes to the dense queue
     // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame, [1] = running count of blocks the
-    // one-wave kernel had to shade through its slow path, [2] = items the dense kernel found.  The host reads it
+    // one-wave kernel had to shade through its slow path, [2] = items the dense kernel found, [3] = sequence number
+    // of the frame that wrote [0].  The host reads it
     // frames later to decide whether the (mostly empty, ~12 us) dense launch can be dropped; `no_dense` tells the
     // one-wave kernel that no dense kernel follows, so it must shade everything itself.
     uint32_t *feedback;
+    uint32_t frame_seq;              // written to feedback[3] after feedback[0]: which frame the report is from
     int no_dense;
     // Work queues of the one-wave kernel: a wave's first block is static (item = wave), the blocks beyond the grid size
     // are pulled from RQ_N counters RQ_STRIDE words apart (item G + q + RQ_N*m is the m-th of queue q).  `rq` is this

@@ -446,7 +446,10 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     const uint32_t lane = threadIdx.x, wave = blockIdx.x, G = gridDim.x;
     const uint64_t npix = (uint64_t)R.width * R.height;
     const uint32_t n_active = *C.n_active, n_dense_cells = *C.n_dense;
-    if (C.feedback && wave == 0 && lane == 0) C.feedback[0] = n_dense_cells;
+    if (C.feedback && wave == 0 && lane == 0) {
+        __hip_atomic_store(&C.feedback[0], n_dense_cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&C.feedback[3], C.frame_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // without a dense kernel behind it this kernel also walks the dense cells (slow path for what does not fit)
     const uint32_t n_shade = (n_active + (C.no_dense ? n_dense_cells : 0u)) * 16u;
 

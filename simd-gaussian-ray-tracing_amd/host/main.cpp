@@ -145,6 +145,7 @@ int main(int argc, char **argv)
     cam.turn(angle, 0.f);
 
     f32 total_time = 0.f;
+    double t_first = 0.0;
     for (u64 frames = 1;; ++frames) {
         const f32 origin[3] = { cam.position[0], cam.position[1], cam.position[2] };
         // rays for this camera pose (the reference rebuilds the plane arrays in cam.turn(), outside its timers)
@@ -155,14 +156,24 @@ int main(int argc, char **argv)
             chk(vrt_hip_set_camera(ctx, (u32)width, (u32)height, cam.position.data(), cam.right.data(), cam.up.data(),
                                    cam.front.data(), cam.focal_length), "set_camera");
 
+        // Tiled modes: tile_gaussians + render in one call on the context's stream.  A frame whose image is needed on
+        // the host (PNG) or whose time is printed is waited for; the frames of an animation that only reports its
+        // average (main.cpp:310-315) are enqueued back to back and the clock stops after the last one.
+        const bool need_image = cmd.outfile != nullptr;
+        const bool trace = getenv("VRT_CLI_TRACE") != nullptr; // per-frame times on stderr (waits for every frame)
+        const bool trace_async = trace && atoi(getenv("VRT_CLI_TRACE")) == 2;
+        const bool wait = need_image || cmd.nr_frames == 1 || (trace && !trace_async);
         double t0 = now_ms();
-        if (use_tiling) chk(vrt_hip_tile_gaussians_device(ctx, 2.f / cmd.tiles, 2.f / cmd.tiles, cam.view_matrix.data(), nullptr), "tile_gaussians");
-        else chk(vrt_hip_clear_tiles(ctx), "clear_tiles");
-        const f32 tiling_time = (f32)(now_ms() - t0);
-
-        t0 = now_ms();
-        chk(vrt_hip_render(ctx, origin, pack, image.data(), nullptr), "render");
-        const f32 draw_time = (f32)(now_ms() - t0);
+        if (frames == 1) t_first = t0;
+        if (use_tiling) {
+            chk(vrt_hip_frame(ctx, 2.f / cmd.tiles, 2.f / cmd.tiles, cam.view_matrix.data(), origin, pack,
+                              need_image ? image.data() : nullptr, wait ? 1 : 0), "frame");
+        } else {
+            chk(vrt_hip_clear_tiles(ctx), "clear_tiles");
+            chk(vrt_hip_render(ctx, origin, pack, need_image ? image.data() : nullptr, nullptr), "render");
+        }
+        const f32 frame_time = (f32)(now_ms() - t0);
+        if (trace) fprintf(stderr, "frame %llu angle %g: %g ms\n", (unsigned long long)frames, angle, frame_time);
 
         if (cmd.outfile != nullptr) { // main.cpp:299-307: <stem>_<frame>.<ext> when more than one frame
             const std::string of(cmd.outfile);
@@ -172,9 +183,13 @@ int main(int argc, char **argv)
             if (!png::write_rgba(path.c_str(), (u32)width, (u32)height, image.data(), width * 4))
                 fprintf(stderr, "[ ERROR ]\tcould not write %s\n", path.c_str());
         }
-        if (cmd.nr_frames == 1) printf("TIME: %g ms\n", draw_time + tiling_time);
-        total_time += draw_time + tiling_time;
+        if (cmd.nr_frames == 1) printf("TIME: %g ms\n", frame_time);
+        total_time += frame_time;
         if (cmd.nr_frames == frames) {
+            const double ts = now_ms();
+            chk(vrt_hip_sync(ctx), "sync");
+            if (trace) fprintf(stderr, "final sync: %g ms\n", now_ms() - ts);
+            if (!wait) total_time = (f32)(now_ms() - t_first); // frames were not waited for one by one
             if (cmd.nr_frames > 1) printf("AVG. TIME: %g ms (%llu frames)\n", total_time / cmd.nr_frames, (unsigned long long)cmd.nr_frames);
             break;
         }
