@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvrt_hip.so")
+LIB_PATH = os.environ.get("VRT_HIP_LIB") or os.path.join(_HERE, "lib", "libvrt_hip.so")   # override: A/B builds
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 EXP_LIBM, EXP_VCL, EXP_FAST, EXP_SPLINE = 0, 1, 2, 3

@@ -74,7 +74,7 @@ struct vrt_hip_ctx {
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
-    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_overflow, c_counters, c_rq;
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_counters, c_rq;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
     int render_waves_per_cu = 12; // persistent one-wave workgroups per CU (LDS allows 13); VRT_HIP_RENDER_WAVES overrides
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
@@ -311,7 +311,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
     g.cells_x = c->cells_x; g.cells_y = c->cells_y; g.cstride = c->cstride;
     g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.n_cells = c->n_cells;
-    g.dense = c->c_dense.p; g.dense_sorted = c->c_dense_sorted.p;
+    g.dense = c->c_dense.p; g.dense_sorted = c->c_dense_sorted.p; g.scratch = c->c_scratch.p;
     g.n_active = cnt; g.n_dense = cnt + 2;
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
@@ -345,6 +345,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     HIPCHK(c, c->c_count.reserve(c->n_cells)); HIPCHK(c, c->c_active.reserve(c->n_cells));
     HIPCHK(c, c->c_dense.reserve(c->n_cells));
     HIPCHK(c, c->c_dense_sorted.reserve(c->n_cells));
+    HIPCHK(c, c->c_scratch.reserve((size_t)c->num_cus * 4 * c->cstride)); // one slot per dense workgroup (<= 4 per CU)
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
     if (!c->c_counters.p) {
@@ -629,7 +630,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
-    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_overflow.release(); c->c_counters.release(); c->c_rq.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_counters.release(); c->c_rq.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);

@@ -12,7 +12,10 @@ constexpr int CELL = 32;          // second-level cull region: 32x32 pixels = 4x
 constexpr int TCAP = 1024;        // a tile's candidates kept in LDS by the fused list kernel
 constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate cell kernel (one wave per cell)
 constexpr int PCAP = 128;         // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each)
-constexpr int DCAP = 1024;        // per-block candidates the dense kernel keeps in LDS
+#ifndef VRT_DCAP
+#define VRT_DCAP 1024
+#endif
+constexpr int DCAP = VRT_DCAP;        // per-block candidates the dense kernel keeps in LDS (61 KB with the rest; the kernel slows by 4 % per 20 KB of LDS beyond that)
 constexpr int PL = 48;            // per-lane list capacity (u8 positions into the block's candidates)
 
 // Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
@@ -43,6 +46,7 @@ struct CellGrid {
     uint32_t n_cells;                // cells of all local tiles
     uint32_t *active;                // cell ids with short lists: shaded one wavefront per block
     uint32_t *dense;                 // cell ids with long lists: shaded one 16-wave workgroup per block
+    uint32_t *scratch;               // dense kernel: cstride words per workgroup (a block's survivors when they outgrow LDS)
     uint32_t *dense_sorted;          // the same, longest list first (order_dense_kernel): the queue order of the dense kernel
     uint32_t *n_active, *n_dense;    // device counters, zeroed before the list kernels add to them
     uint32_t *dense_next;            // work counter of the dense kernel (zeroed with the others)

@@ -631,10 +631,21 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                                                                 RenderTarget O)
 {
     constexpr int DCAP = vrtk::DCAP;
-    __shared__ uint32_t s_idx0[DCAP], s_idx[DCAP];   // "0": in list order; the others: sorted by depth
-    __shared__ float4 s_A[DCAP], s_B[DCAP];          // 60 KB with the rest: two 8-wave workgroups fit a CU's 160 KB
-    __shared__ float s_key[DCAP];
-    __shared__ float4 s_L[DW][64];
+    // One block of LDS carved by hand: the two rows the absorber loop reads sit in the first 64 KB, where a DS
+    // instruction's 16-bit offset field reaches them (arrays placed beyond cost a VALU address add per read: +4 %).
+    struct Lds {
+        float4 A[DCAP], B[DCAP];          // sorted by depth
+        float4 L[DW][64];
+        uint32_t idx0[DCAP], idx[DCAP];   // "0": in list order; idx: sorted
+        float key[DCAP];
+    };
+    __shared__ Lds lds;
+    float4(&s_A)[DCAP] = lds.A;
+    float4(&s_B)[DCAP] = lds.B;
+    float4(&s_L)[DW][64] = lds.L;
+    uint32_t(&s_idx0)[DCAP] = lds.idx0;
+    uint32_t(&s_idx)[DCAP] = lds.idx;
+    float(&s_key)[DCAP] = lds.key;
     __shared__ uint32_t s_wave_cnt[DW];
     __shared__ uint32_t s_item;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -643,6 +654,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
     constexpr float SAT_M = SAT + 1e-3f; // the range bounds are re-associated forms of the arguments: keep a margin
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
     if (C.feedback && blockIdx.x == 0 && tid == 0) C.feedback[2] = n_items;
+    uint32_t *scratch = C.scratch + (size_t)blockIdx.x * C.cstride;
     const unsigned long long t_start = O.stats ? wall_clock64() : 0ull;
 
     for (;;) {
@@ -713,6 +725,9 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                 s_idx0[pos] = idx;
                 s_key[pos] = a.x * cone.cx + a.y * cone.cy + a.z * cone.cz; // depth along the block's axis
             }
+            // the survivors also go to this workgroup's slot of global scratch: should they outgrow LDS, the fallback
+            // below streams THEM (cnt^2 pairs) and not the whole cell list (n_list^2)
+            if (keep && pos < C.cstride) scratch[pos] = idx;
             cnt += chunk;
             __syncthreads();
         }
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
         }
         __syncthreads();
         if (O.stats && tid == 0) {
-            atomicAdd(&O.stats[0], (unsigned long long)(cnt <= DCAP ? cnt : n_list));
+            atomicAdd(&O.stats[0], (unsigned long long)(cnt <= C.cstride ? cnt : n_list));
             atomicAdd(&O.stats[1], (unsigned long long)n_list);
             if (cnt > DCAP) atomicAdd(&O.stats[2], 1ull);
             atomicAdd(&O.stats[6], 1ull);
@@ -740,8 +755,11 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
 
         float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
         if (cnt > DCAP) {
-            // does not fit LDS: every wave streams the whole list through scalar loads for its share of the emitters
-            shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La, wave * 4, DW * 4);
+            // does not fit LDS: every wave streams the block's survivors (written above by this workgroup: visible to
+            // all its waves after the barrier + fence) for its share of the emitters
+            __threadfence_block();
+            if (cnt <= C.cstride) shade_list<EXP, ERF, 4, true>(S, scratch, cnt, ray, Lr, Lg, Lb, La, wave * 4, DW * 4);
+            else shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La, wave * 4, DW * 4);
         } else {
             for (uint32_t i0 = wave * EC; i0 < cnt; i0 += DW * EC) {
                 float e_mubar[EC], e_sigma[EC];
