@@ -36,7 +36,7 @@ def load_pkg():
 
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_WAVE_INSTR = 1024 / 1.24e-9   # measured on MI355X (scratch/ubench/valu.hip): one v_fma_f32 wave-instruction
+VALU_PEAK_WAVE_INSTR = 1024 / 1.24e-9   # measured on MI355X (tools/ubench/valu.hip): one v_fma_f32 wave-instruction
                                         # per 1.24 ns per SIMD with >= 2 waves/SIMD, 1024 SIMDs (= 5.3e13 lane-ops/s)
 
 
