@@ -15,7 +15,7 @@ constexpr int PCAP = 128;         // per-block candidates cached in LDS (four pa
 #ifndef VRT_DCAP
 #define VRT_DCAP 1024
 #endif
-constexpr int DCAP = VRT_DCAP;        // per-block candidates the dense kernel keeps in LDS (61 KB with the rest; the kernel slows by 4 % per 20 KB of LDS beyond that)
+constexpr int DCAP = VRT_DCAP;        // per-block candidates the dense kernel keeps in LDS (61 KB with the rest; measured: no change below 64 KB, +4 % at 81 KB, +10 % at 104 KB)
 constexpr int PL = 48;            // per-lane list capacity (u8 positions into the block's candidates)
 
 // Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
