@@ -159,6 +159,13 @@ int vrt_hip_density(vrt_hip_ctx *ctx, size_t npts, const float *pts, float *D_ou
 int vrt_hip_eval_erf(vrt_hip_ctx *ctx, int erf_kind, const float *x, size_t n, float *y);
 int vrt_hip_eval_exp(vrt_hip_ctx *ctx, int exp_kind, const float *x, size_t n, float *y);
 
+/* Opt-in approximation for dense scenes (NOT the reference's sum; inside its tolerance): blocks with many overlapping
+ * Gaussians evaluate the transmittance exponent of a ray at 160 nodes along it and interpolate the 5 n sample points
+ * (n * 160 erf terms per ray instead of 5 n^2).  `step` = largest allowed node spacing in units of sqrt2 * sigma
+ * (0 = off, the default; 0.08 keeps the exponent within ~2e-5); blocks that 160 nodes cannot cover at that spacing
+ * are shaded exactly.  See render_table_kernel in csrc/vrt_kernels.hip. */
+int vrt_hip_set_table_step(vrt_hip_ctx *ctx, float step);
+
 /* -------- statistics of the last render ----------------------------------------------------- */
 typedef struct {
     double kernel_ms;        /* render kernel time of the last vrt_hip_render() (HIP events)       */
@@ -173,6 +180,7 @@ typedef struct {
     uint64_t shaded_blocks;  /* blocks that reached the shading loops (the rest were only cleared)    */
     uint64_t dense_blocks;   /* of those, blocks shaded by the 16-waves-per-block kernel              */
     double dense_busy_frac;  /* mean share of that kernel's duration its workgroups had blocks to work on */
+    uint64_t table_blocks;   /* of the dense blocks, those shaded through the interpolation table (vrt_hip_set_table_step) */
     uint64_t slow_path_total;/* running count (since create) of blocks the one-wave kernel had to shade through its
                                 one-wave-streams-the-whole-list fallback because no dense kernel was launched behind it */
 } vrt_hip_stats;

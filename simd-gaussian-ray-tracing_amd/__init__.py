@@ -34,7 +34,8 @@ class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("tiling_ms", C.c_double), ("rays", C.c_uint64), ("blocks", C.c_uint64),
                 ("list_entries", C.c_uint64), ("tile_entries", C.c_uint64), ("overflow_blocks", C.c_uint64),
                 ("lane_entries", C.c_uint64), ("lane_max_entries", C.c_uint64), ("shaded_blocks", C.c_uint64), ("dense_blocks", C.c_uint64),
-                ("dense_busy_frac", C.c_double), ("slow_path_total", C.c_uint64)]
+                ("dense_busy_frac", C.c_double), ("table_blocks", C.c_uint64),
+                ("slow_path_total", C.c_uint64)]
 
 
 def build(verbose=False):
@@ -68,6 +69,7 @@ SYMBOLS = {
     "vrt_hip_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
     "vrt_hip_shard_pixels": (C.c_size_t, [_vp]),
     "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
+    "vrt_hip_set_table_step": (C.c_int, [_vp, C.c_float]),
     "vrt_hip_frame": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, C.c_int]),
     "vrt_hip_sync": (C.c_int, [_vp]),
     "vrt_hip_assemble_shards_device": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -301,6 +303,10 @@ class Renderer:
 
     def enable_stats(self, on=True):
         self._chk(self._L.vrt_hip_enable_stats(self._h, int(on)), "enable_stats")
+
+    def set_table_step(self, step):
+        """Opt-in table mode for dense blocks (0 = off): see vrt_hip_set_table_step in include/vrt_hip.h."""
+        self._chk(self._L.vrt_hip_set_table_step(self._h, float(step)), "set_table_step")
 
     def enable_kernel_timing(self, on=True):
         self._chk(self._L.vrt_hip_enable_kernel_timing(self._h, int(on)), "enable_kernel_timing")

@@ -74,7 +74,7 @@ struct vrt_hip_ctx {
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
-    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_counters, c_rq;
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
     int render_waves_per_cu = 12; // persistent one-wave workgroups per CU (LDS allows 13); VRT_HIP_RENDER_WAVES overrides
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
@@ -91,6 +91,7 @@ struct vrt_hip_ctx {
     // that wrote it) newer than reset_seq comes from the current scene / camera / options
     uint32_t frame_seq = 0, reset_seq = 0;
     int num_cus = 256;
+    float table_hx = 0.f;  // vrt_hip_set_table_step(): 0 = the exact kernels only
     int dense_waves = 16; // waves per block in the dense kernel (tuning knob: VRT_HIP_DENSE_WAVES = 4 | 8 | 16)
     bool work_is_ref = false; // render straight from the ref lists (no tile-level cull possible)
     bool lists_dirty = true;
@@ -315,6 +316,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.n_active = cnt; g.n_dense = cnt + 2;
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
+    g.table_hx = c->table_hx; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
     g.feedback = c->d_fb;
     g.no_dense = 0;
@@ -347,6 +349,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     HIPCHK(c, c->c_dense_sorted.reserve(c->n_cells));
     HIPCHK(c, c->c_scratch.reserve((size_t)c->num_cus * 4 * c->cstride)); // one slot per dense workgroup (<= 4 per CU)
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
+    if (c->table_hx > 0.f) HIPCHK(c, c->c_overflow2.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
     if (!c->c_counters.p) {
         HIPCHK(c, c->c_counters.reserve(16));
@@ -510,7 +513,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     // persistent grid: 12 one-wave workgroups per CU (three per SIMD at 145 VGPRs), never more than there are blocks
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * c->render_waves_per_cu);
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
-        HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1) + 3, 0, 2 * sizeof(uint32_t), st));
+        HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1) + 3, 0, 4 * sizeof(uint32_t), st));
     c->lists_fresh = false;
     // Is the dense launch worth its ~12 us?  Frames report (asynchronously, see CellGrid::feedback) how many dense
     // cells / slow-path blocks they had; a few frames after the last change of scene or options the report of
@@ -539,10 +542,21 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
     // dense queue: one 16-wave workgroup per CU pulls blocks until the queue is empty (exits at once if it is)
     if (launch_dense) launch_order_dense(cg, st);
-    if (launch_dense)
-        launch_render_dense(tables(c), t, cg, ray_gen(c, origin), o,
-                            (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16))),
-                            c->dense_waves, c->exp_kind, c->erf_kind, st);
+    if (launch_dense) {
+        const uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
+        if (c->table_hx > 0.f) {
+            // opt-in table mode: the table kernel takes the whole dense queue and hands what it declines to a second
+            // queue, which the exact kernel then works off (n_dense reads the always-zero word of the counter set)
+            launch_render_table(tables(c), t, cg, ray_gen(c, origin), o, std::min<uint32_t>(dense_grid, (uint32_t)c->num_cus), c->exp_kind, c->erf_kind, st);
+            CellGrid cq = cg;
+            uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
+            cq.n_dense = cnt + 7; cq.n_overflow = cnt + 5; cq.overflow = c->c_overflow2.p; cq.dense_next = cnt + 6;
+            cq.feedback = nullptr;
+            launch_render_dense(tables(c), t, cq, ray_gen(c, origin), o, dense_grid, c->dense_waves, c->exp_kind, c->erf_kind, st);
+        } else {
+            launch_render_dense(tables(c), t, cg, ray_gen(c, origin), o, dense_grid, c->dense_waves, c->exp_kind, c->erf_kind, st);
+        }
+    }
     if (tev) {
         if (c->timing_full) HIPCHK(c, hipEventRecord(tev[3], st));
         ++c->timing_count;
@@ -630,7 +644,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
-    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_counters.release(); c->c_rq.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_overflow2.release(); c->c_counters.release(); c->c_rq.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
@@ -696,6 +710,15 @@ int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_e
     if (exp_kind != c->exp_kind || cull_eps != c->cull_eps) c->tables_dirty = true;
     if (exp_kind != c->exp_kind || erf_kind != c->erf_kind || cull_eps != c->cull_eps) c->reset_seq = c->frame_seq;
     c->exp_kind = exp_kind; c->erf_kind = erf_kind; c->cull_eps = cull_eps;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_table_step(vrt_hip_ctx *c, float hx)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!(hx >= 0.f) || hx > 1.f) return fail(c, VRT_HIP_ERR_INVALID, "set_table_step: step must be in [0, 1]");
+    if (hx != c->table_hx) { c->reset_seq = c->frame_seq; c->lists_dirty = true; }
+    c->table_hx = hx;
     return VRT_HIP_OK;
 }
 
@@ -919,6 +942,7 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
         c->last.dense_busy_frac = (st[11] && st[9] > st[8]) ? (double)st[10] / ((double)st[11] * (double)(st[9] - st[8])) : 0.0;
         c->last.shaded_blocks = st[5] + st[6];
         c->last.dense_blocks = st[6];
+        c->last.table_blocks = st[7];
         c->last.list_entries = st[0]; c->last.tile_entries = st[1]; c->last.overflow_blocks = st[2];
         c->last.lane_entries = st[3]; c->last.lane_max_entries = st[4];
     }

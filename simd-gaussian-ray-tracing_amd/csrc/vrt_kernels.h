@@ -65,6 +65,10 @@ struct CellGrid {
     // are pulled from RQ_N counters RQ_STRIDE words apart (item G + q + RQ_N*m is the m-th of queue q).  `rq` is this
     // launch's set (zero on entry), `rq_next` the other set, which this launch clears for the next one.
     uint32_t *rq, *rq_next;
+    // table mode (render_table_kernel): node spacing limit in units of 1/r (0 = off) and the queue of the blocks it
+    // declines, which the exact dense kernel works off afterwards
+    float table_hx;
+    uint32_t *overflow2, *n_overflow2;
 };
 constexpr uint32_t RQ_N = 8, RQ_STRIDE = 64;
 
@@ -102,6 +106,8 @@ void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGri
                          const RenderTarget &o, uint32_t grid, int dw /* waves per block: 4, 8 or 16 */, int exp_kind,
                          int erf_kind, hipStream_t st);
 void launch_order_dense(const CellGrid &c, hipStream_t st);
+void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                         const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
 void launch_build_cell_lists(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                              const uint32_t *tile_map, uint32_t n_cells, int refine, hipStream_t st);
 

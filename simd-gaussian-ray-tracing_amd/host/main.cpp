@@ -35,7 +35,10 @@
     "\t--mode <mode>, -m <mode>:               Set the rendering mode to <mode> (1-4 without, 5-8 with tiling;\n"\
     "\t                                        selects the packing convention and Exp/Erf pair of that mode).\n"\
     "\t--plane-arrays:                         Feed the projection-plane arrays like the reference (default: in-kernel rays).\n"\
-    "\t--cull-eps <eps>:                       Culling threshold (default 1e-9; 0 = the reference's full sum).\n"
+    "\t--cull-eps <eps>:                       Culling threshold (default 1e-9; 0 = the reference's full sum).\n"\
+    "\t--table-step <step>:                    Opt-in approximation for dense scenes: interpolate the transmittance along\n"\
+    "\t                                        each ray from 160 nodes no farther apart than <step>*sqrt2*sigma (0 = off,\n"\
+    "\t                                        the default; 0.12 keeps the radiance within 1e-5 on the test objects).\n"
 
 struct cmd_args_t { // main.cpp:54-184
     u64 w = (u64)-1, h = (u64)-1;
@@ -43,7 +46,7 @@ struct cmd_args_t { // main.cpp:54-184
     char *outfile = nullptr, *infile = nullptr;
     bool use_grid = false;
     u64 thread_count = 1, nr_frames = 1, tiles = 16, mode = 8;
-    f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f;
+    f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f, table_step = 0.f;
     bool plane_arrays = false;
     cmd_args_t(int argc, char **argv)
     {
@@ -56,7 +59,8 @@ struct cmd_args_t { // main.cpp:54-184
             { "rotation", required_argument, NULL, 'r' }, { "initial-rotation", required_argument, NULL, 'i' },
             { "camera-offset", required_argument, NULL, 'c' }, { "focal-length", required_argument, NULL, 0xfe },
             { "help", no_argument, NULL, 0xff }, { "plane-arrays", no_argument, NULL, 0xfd },
-            { "cull-eps", required_argument, NULL, 0xfc }, { NULL, 0, NULL, 0 }
+            { "cull-eps", required_argument, NULL, 0xfc }, { "table-step", required_argument, NULL, 0xfb },
+            { NULL, 0, NULL, 0 }
         };
         int lidx;
         for (;;) {
@@ -79,6 +83,7 @@ struct cmd_args_t { // main.cpp:54-184
             case 0xfe: focal_length = strtof(optarg, NULL); break;
             case 0xfd: plane_arrays = true; break;
             case 0xfc: cull_eps = strtof(optarg, NULL); break;
+            case 0xfb: table_step = strtof(optarg, NULL); break;
             case 'm': mode = strtoul(optarg, NULL, 10); if (mode < 1 || mode > 8) mode = 8; break;
             default: break;
             }
@@ -132,6 +137,7 @@ int main(int argc, char **argv)
     };
     chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians");
     chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options");
+    chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step");
 
     const u64 width = cmd.w, height = cmd.h;
     std::vector<u32> image(width * height);

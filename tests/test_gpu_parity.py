@@ -565,3 +565,38 @@ def test_frames_enqueued_back_to_back_with_a_moving_camera(pkg, oracle, renderer
         renderer.enable_stats(False)
         np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32).reshape(h, w), img)
     assert dense_seen      # the orbit does pass through views that need the dense kernel
+
+
+@pytest.mark.parametrize("name,step,rot", [("monkey", 0.12, 20.0), ("monkey", 0.12, 150.0), ("teapot", 0.2, 0.0)])
+def test_table_mode_stays_inside_the_tolerance(pkg, oracle, renderer, name, step, rot):
+    """Opt-in table mode (vrt_hip_set_table_step): dense blocks interpolate the transmittance exponent from 160 nodes per
+    ray.  Not the reference's sum, but within its 1e-4 tolerance of the ORACLE on the bright pixels of the test objects,
+    within 5e-5 of the exact kernels over the whole frame, and blocks it cannot cover are shaded exactly."""
+    w = h = 512
+    g = oracle.read_obj(os.path.join(GOLDEN, "test-objects", name + ".obj"))
+    cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h, rot=rot)
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    _, exact = renderer.render(origin)
+    renderer.set_table_step(step)
+    try:
+        renderer.enable_stats(True)
+        img, rad = renderer.render(origin)
+        st = renderer.stats()
+        renderer.enable_stats(False)
+        assert st["table_blocks"] > 0 and st["table_blocks"] <= st["dense_blocks"]
+        assert np.abs(rad - exact).max() <= 5e-5
+        rng = np.random.default_rng(7)
+        lum = rad.reshape(-1, 4)[:, :3].sum(1)
+        pix = np.unique(rng.choice(np.nonzero(lum > 0.05)[0], 40)).astype(np.uint32)
+        _, orad = oracle.render(w, h, plane, origin, g, tiles, pixels=pix, want_image=False)
+        assert np.abs(rad.reshape(-1, 4)[pix] - orad).max() <= TOL
+        # a step nothing can meet: every block declined, the exact kernel behind the table kernel shades them all
+        renderer.set_table_step(1e-4)
+        renderer.enable_stats(True)
+        _, rad2 = renderer.render(origin)
+        st2 = renderer.stats()
+        renderer.enable_stats(False)
+        assert st2["table_blocks"] == 0 and st2["dense_blocks"] == st["dense_blocks"]
+        np.testing.assert_array_equal(rad2, exact)
+    finally:
+        renderer.set_table_step(0.0)
