@@ -966,7 +966,7 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
         }
         float h = (s_hi - s_lo) / (float)(G - 5);
         s_lo -= 2.f * h; // two nodes of margin at either end: every sample has its four neighbours
-        ok = ok && __all(!(h * r_max > C.table_hx)); // (also false for NaN)
+        ok = ok && __all(h * r_max <= C.table_hx); // (false for NaN)
         if (!ok) { // wave-uniform and the same in every wave
             if (tid == 0) C.overflow2[atomicAdd(C.n_overflow2, 1u)] = (cell << 4) | bi;
             continue;
