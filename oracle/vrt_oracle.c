@@ -651,6 +651,11 @@ void oracle_render_image_tiled(uint32_t w, uint32_t h, uint32_t *image, float *r
         const size_t i = pixels ? pixels[q] : q;
         const uint64_t row = i / stride, col = i % stride;
         const uint64_t tx = col / tile_width, ty = row / tile_height;
+        if (ty >= tiles_h || tile_width == 0 || i >= (size_t)w * h) { /* a listed index outside the tile grid: not a pixel the reference renders */
+            const float z[4] = { 0.f, 0.f, 0.f, 0.f };
+            if (radiance_out) memcpy(radiance_out + 4 * q, z, sizeof z);
+            continue;
+        }
         const size_t t = (size_t)(ty * tiles_w + tx);
         const ovec4 c = shade(i, xs, ys, zs, o, sets[t], offsets[t + 1] - offsets[t], exp_kind, erf_kind);
         const float cf[4] = { c.x, c.y, c.z, c.w };
