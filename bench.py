@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--tiles", type=int, default=16)
     ap.add_argument("--cull-eps", type=float, default=1e-9)
     ap.add_argument("--gather-frames", type=int, default=16, help="N > 1: frames per RCCL gather (one collective per batch)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plane-arrays", action="store_true", help="feed reference-style plane arrays (12 B/ray reads)")
     args = ap.parse_args()
@@ -133,22 +135,39 @@ def main():
     tw = th = 2.0 / args.tiles
     pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
 
-    r = pkg.Renderer(local_rank)
-    r.set_gaussians(g)
-    if args.plane_arrays:
-        r.set_plane(w, h, *cam.plane())
-    else:
-        r.set_camera(w, h, cam.position, cam.right, cam.up, cam.front, float(cam.focal))
-    r.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
-    r.set_shard(rank, world)
-    stream = torch.cuda.current_stream()
-    sp = stream.cuda_stream
-    r.tile_gaussians_device(tw, th, view, sp)   # also sizes the tile grid (one-time host sync)
+    # N = 1: the frames alternate between `--frames-in-flight` library contexts, each on its own HIP stream (default 2):
+    # frame k+1's list kernel and the head of its render kernel run while frame k's render kernel drains -- the
+    # double-buffered frame loop of any renderer.  Every frame does all of its work; the strictly serial figures are
+    # measured after the timed region and reported next to the headline ("serial").  N > 1: one context per rank
+    # (the frame rate is set by the gather there).
+    nctx = max(1, args.frames_in_flight) if world == 1 else 1
+
+    def make_renderer():
+        r_ = pkg.Renderer(local_rank)
+        r_.set_gaussians(g)
+        if args.plane_arrays:
+            r_.set_plane(w, h, *cam.plane())
+        else:
+            r_.set_camera(w, h, cam.position, cam.right, cam.up, cam.front, float(cam.focal))
+        r_.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
+        r_.set_shard(rank, world)
+        return r_
+
+    ctxs = [make_renderer() for _ in range(nctx)]
+    r = ctxs[0]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nctx - 1)]
+    sps = [s_.cuda_stream for s_ in streams]
+    sp = sps[0]
+    for r_, sp_ in zip(ctxs, sps):
+        r_.tile_gaussians_device(tw, th, view, sp_)   # also sizes the tile grid (one-time host sync)
     torch.cuda.synchronize()
 
-    image = torch.zeros(w * h, dtype=torch.int32, device="cuda")
-    frame = r.frame_call(tw, th, view, origin, pack, shard=world > 1)   # tile_gaussians + render, one C call
-    img_ptr = image.data_ptr()
+    images = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(nctx)]
+    image = images[0]
+    frames = [r_.frame_call(tw, th, view, origin, pack, shard=world > 1) for r_ in ctxs]   # tile_gaussians + render, one C call
+    frame = frames[0]
+    img_ptrs = [im.data_ptr() for im in images]
+    img_ptr = img_ptrs[0]
     # N > 1: sharding.FrameGatherer -- every rank renders its tile shard of F consecutive frames into one buffer, ONE
     # gather per F frames moves them to rank 0 (double-buffered against the next batch's rendering), rank 0 assembles
     # every gathered frame into raster order.  The same class runs under gloo in tests/test_dist_gloo.py.
@@ -166,10 +185,11 @@ def main():
         def assemble(b, f):
             r.assemble_shards_device(gath_ptr[b] + 4 * f * npx, img_ptr, sp, rank_stride_px=F * npx)
 
-    def run(nsteps):
+    def run(nsteps, in_flight=nctx):
         if world == 1:
-            for _ in range(nsteps):
-                frame(img_ptr, sp)
+            for k in range(nsteps):
+                i = k % in_flight
+                frames[i](img_ptrs[i], sps[i])
         else:
             fg.run(nsteps, render_shard, assemble)
 
@@ -191,12 +211,20 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kt = r.kernel_timing()
+    r.enable_kernel_timing(False)
+    # after the timed region: strictly serial frames on one context (no events), then the per-kernel breakdown
+    n_serial = min(args.steps, 400)
+    barrier()
+    t1 = time.perf_counter()
+    run(n_serial, 1)
+    barrier()
+    serial_ms = (time.perf_counter() - t1) / max(n_serial, 1) * 1e3
     r.enable_kernel_timing(1)
-    run(min(args.steps, 100))
+    run(min(args.steps, 100), 1)
     barrier()
     seq = r.kernel_timing()
     r.enable_kernel_timing(False)
-    kt["lists_ms"], kt["dense_ms"] = seq["lists_ms"], seq["dense_ms"]
+    kt["lists_ms"], kt["dense_ms"], kt["render_serial_ms"] = seq["lists_ms"], seq["dense_ms"], seq["render_ms"]
 
     red_dev = "cuda" if backend == "nccl" else "cpu"
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -217,7 +245,7 @@ def main():
         r.set_shard(0, 1)
         _img, _ = r.render(origin, pack, want_radiance=False)
         # the gathered + assembled frame of the timed loop must be the single-GPU frame, bit for bit
-        frame_ok = bool((image.cpu().numpy().view(np.uint32) == _img.reshape(-1)).all())
+        frame_ok = all(bool((im.cpu().numpy().view(np.uint32) == _img.reshape(-1)).all()) for im in images)
         st = r.stats()
         r.enable_stats(False)
         r.set_shard(rank, world)
@@ -240,10 +268,13 @@ def main():
                 traffic = pmc["render_kernel_traffic_bytes_per_launch"]["lower"]
                 traffic_frame = pmc["frame_hbm_bytes"]["write"] + pmc["frame_hbm_bytes"]["fetch_raw"]
                 nv = pmc.get("sq_counters_bench_scene_per_launch", {}).get("render_kernel", {}).get("SQ_INSTS_VALU")
+                nl = pmc.get("sq_counters_bench_scene_per_launch", {}).get("build_tile_lists_kernel", {}).get("SQ_INSTS_VALU", 0.0)
                 if nv:
                     rate = nv / (kernel_ms * 1e-3)
+                    frame_rate = (nv + nl) / (ms_per_step * 1e-3)   # all VALU work of a frame over the frame time
                     valu = {"wave_instructions_per_launch": nv, "achieved_per_s": rate, "peak_per_s": VALU_PEAK_WAVE_INSTR,
-                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01c_pmc_traffic.json (SQ_INSTS_VALU)"}
+                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01c_pmc_traffic.json (SQ_INSTS_VALU)",
+                            "frame": {"wave_instructions": nv + nl, "achieved_per_s": frame_rate, "frac": frame_rate / VALU_PEAK_WAVE_INSTR}}
         except (OSError, KeyError, ValueError):
             pass
         result = {
@@ -254,6 +285,7 @@ def main():
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
                        "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
                        "parallelism": f"tile-shard x{world}" + (f" + RCCL gather to rank 0 every {F} frames" if world > 1 else ""),
+                       "frames_in_flight": nctx,
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": render_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -261,12 +293,17 @@ def main():
                          # an event pair with nothing between reads ~4.6 us on this stack: rocprofv3's kernel duration
                          # (profiles/) is the event figure minus that.  `achieved` uses the raw (larger) event figure.
                          "event_pair_overhead_ms": kt["dense_ms"] if st["dense_blocks"] == 0 else None,
-                         "launch_sequence_ms": {"lists": kt["lists_ms"], "render_kernel": kt["render_ms"],
+                         # strictly serial frames, after the timed region: four events per frame
+                         "launch_sequence_ms": {"lists": kt["lists_ms"], "render_kernel": kt["render_serial_ms"],
                                                 "render_dense_kernel": kt["dense_ms"]},
                          "frame": {"algorithmic_bytes": frame_bytes, "ms": frame_ms, "achieved": frame_gbs,
                                    "frac": frame_gbs / HBM_PEAK_GBS, "traffic": traffic_frame},
                          "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4): see valu; "
-                                 "traffic = WRITE_SIZE + raw FETCH_SIZE of separate PMC passes (profiles/)"},
+                                 "traffic = WRITE_SIZE + raw FETCH_SIZE of separate PMC passes (profiles/); with two frames "
+                                 "in flight kernel_ms is the duration of a launch that shares the GPU with the other "
+                                 "context's kernels (launch_sequence_ms: the same kernels alone)"},
+            # the same loop with one context: frame k+1 starts when frame k is done
+            "serial": {"frames_in_flight": 1, "ms_per_step": serial_ms, "value": w * h / (serial_ms * 1e-3) / 1e6, "steps": n_serial},
             "valu": {"issue": valu, "blocks": st["blocks"], "shaded_blocks": st["shaded_blocks"], "dense_blocks": st["dense_blocks"],
                      "mean_cell_list": st["tile_entries"] / sb, "mean_block_list": st["list_entries"] / sb,
                      "mean_ray_list": st["lane_entries"] / (sb * 64), "mean_block_longest_ray_list": st["lane_max_entries"] / sb,
@@ -277,7 +314,8 @@ def main():
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     barrier()
-    r.close()
+    for r_ in ctxs:
+        r_.close()
     if world > 1:
         dist.destroy_process_group()
 
