@@ -7,6 +7,8 @@ Metric (BASELINE.json): Mrays/sec (whole node) + ms/frame, 2048^2 image, 64x64 G
 A step = one frame = what the reference times as `TIME:` (main.cpp:260-296): tile binning of all
 Gaussians + render (+ for N > 1: RCCL gather of the tile shards to rank 0 + assembly into raster
 order).  Inputs (scene tables, camera) are resident in HBM before the timed region starts.
+N = 1 keeps two frames in flight (two library contexts on two HIP streams, --frames-in-flight);
+the strictly serial figures are reported next to the headline under "serial".
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...

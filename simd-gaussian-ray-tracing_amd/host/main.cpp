@@ -126,18 +126,26 @@ int main(int argc, char **argv)
     if (base_mode == 1) { ek = VRT_EXP_LIBM; rk = VRT_ERF_LIBM; }
     if (base_mode == 4) pack = VRT_PACK_ROUND | (use_tiling ? VRT_ALPHA_COMPUTED : VRT_ALPHA_OPAQUE);
 
-    vrt_hip_ctx *ctx = nullptr;
+    // An animation whose frames are not written out keeps two frames in flight: the frames alternate between two
+    // contexts (each has its own HIP stream), so one frame's list kernel overlaps the other's render kernel.
+    const int nctx = (cmd.outfile == nullptr && cmd.nr_frames > 1 && getenv("VRT_CLI_TRACE") == nullptr) ? 2 : 1;
+    vrt_hip_ctx *ctxs[2] = { nullptr, nullptr };
     const char *dev = getenv("VRT_HIP_DEVICE");
-    if (vrt_hip_create(dev ? atoi(dev) : 0, &ctx) != VRT_HIP_OK) {
-        fprintf(stderr, "[ ERROR ]\t%s\n", vrt_hip_last_error(nullptr));
-        return EXIT_FAILURE;
-    }
+    for (int i = 0; i < nctx; ++i)
+        if (vrt_hip_create(dev ? atoi(dev) : 0, &ctxs[i]) != VRT_HIP_OK) {
+            fprintf(stderr, "[ ERROR ]\t%s\n", vrt_hip_last_error(nullptr));
+            return EXIT_FAILURE;
+        }
+    vrt_hip_ctx *ctx = ctxs[0];
     auto chk = [&](int rc, const char *what) {
         if (rc != VRT_HIP_OK) { fprintf(stderr, "[ ERROR ]\t%s: %s\n", what, vrt_hip_last_error(ctx)); exit(EXIT_FAILURE); }
     };
-    chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians");
-    chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options");
-    chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step");
+    for (int i = 0; i < nctx; ++i) {
+        ctx = ctxs[i];
+        chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians");
+        chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options");
+        chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step");
+    }
 
     const u64 width = cmd.w, height = cmd.h;
     std::vector<u32> image(width * height);
@@ -153,6 +161,7 @@ int main(int argc, char **argv)
     f32 total_time = 0.f;
     double t_first = 0.0;
     for (u64 frames = 1;; ++frames) {
+        ctx = ctxs[(frames - 1) % nctx];
         const f32 origin[3] = { cam.position[0], cam.position[1], cam.position[2] };
         // rays for this camera pose (the reference rebuilds the plane arrays in cam.turn(), outside its timers)
         if (cmd.plane_arrays)
@@ -193,7 +202,7 @@ int main(int argc, char **argv)
         total_time += frame_time;
         if (cmd.nr_frames == frames) {
             const double ts = now_ms();
-            chk(vrt_hip_sync(ctx), "sync");
+            for (int i = 0; i < nctx; ++i) { ctx = ctxs[i]; chk(vrt_hip_sync(ctx), "sync"); }
             if (trace) fprintf(stderr, "final sync: %g ms\n", now_ms() - ts);
             if (!wait) total_time = (f32)(now_ms() - t_first); // frames were not waited for one by one
             if (cmd.nr_frames > 1) printf("AVG. TIME: %g ms (%llu frames)\n", total_time / cmd.nr_frames, (unsigned long long)cmd.nr_frames);
@@ -205,6 +214,6 @@ int main(int argc, char **argv)
         angle -= angle_change;
         cam.turn(angle, 0.f);
     }
-    vrt_hip_destroy(ctx);
+    for (int i = 0; i < nctx; ++i) vrt_hip_destroy(ctxs[i]);
     return EXIT_SUCCESS;
 }
