@@ -196,6 +196,16 @@ def main():
             fg.run(nsteps, render_shard, assemble)
 
     def barrier():
+        # poll the streams' completion first: hipDeviceSynchronize alone wakes up ~0.1-0.2 ms after the GPU is done
+        # (interrupt-driven wait), which would be charged to the K timed steps
+        evs = []
+        for s_ in streams:
+            ev = torch.cuda.Event()
+            ev.record(s_)
+            evs.append(ev)
+        for ev in evs:
+            while not ev.query():
+                pass
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

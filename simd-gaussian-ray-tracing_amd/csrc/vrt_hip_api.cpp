@@ -1193,7 +1193,14 @@ int vrt_hip_enable_kernel_timing(vrt_hip_ctx *c, int on)
     c->timing_on = on != 0;
     c->timing_full = on == 1; // 2, 3: events around the one-wave render kernel only (two per frame instead of four)
     c->timing_period = on == 3 ? 8 : 1; // 3: on every 8th frame only
-    if (on) { c->timing_count = 0; c->timing_frame = 0; }
+    if (on) {
+        c->timing_count = 0; c->timing_frame = 0;
+        if (c->tev.empty()) { // here, not in the first timed frame
+            HIPCHK(c, hipSetDevice(c->device));
+            c->tev.resize(4 * vrt_hip_ctx::TIMING_RING);
+            for (auto &e : c->tev) HIPCHK(c, hipEventCreate(&e));
+        }
+    }
     return VRT_HIP_OK;
 }
 
