@@ -150,7 +150,7 @@ def main():
         if args.plane_arrays:
             r_.set_plane(w, h, *cam.plane())
         else:
-            r_.set_camera(w, h, cam.position, cam.right, cam.up, cam.front, float(cam.focal))
+            r_.set_camera_view(w, h, view)   # in-kernel rays = the reference's plane points, bit for bit (camera.cpp:60-69)
         r_.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
         r_.set_shard(rank, world)
         return r_

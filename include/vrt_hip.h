@@ -100,6 +100,13 @@ int vrt_hip_set_plane(vrt_hip_ctx *ctx, uint32_t w, uint32_t h, const float *xs,
  * x = -1 + j/(w/2), y = -1 + i/(h/2) -- the closed form of camera.cpp:52,60-69 (no 12 B/ray read). */
 int vrt_hip_set_camera(vrt_hip_ctx *ctx, uint32_t w, uint32_t h, const float pos[3], const float right[3],
                        const float up[3], const float front[3], float focal);
+/* In-kernel rays, bit for bit the reference's: the projection-plane point of pixel (i, j) is
+ * inverse(view) * (-1 + j/(w/2), -1 + i/(h/2), 0, 1) (camera.cpp:60-69), evaluated per ray with glm's inverse and
+ * glm's mat4*vec4 in their order of operations.  `view` = camera_t::view (column-major, glm layout).  Same image as
+ * vrt_hip_set_plane() with the arrays camera_t would build, without the 12 B per ray.  (vrt_hip_set_camera above
+ * takes the closed form pos + x right + y up - focal front instead: the same rays up to the rounding of the plane
+ * points -- which the reference's |oc|^2 - mubar^2 can amplify to 1e-4 for small sigma.) */
+int vrt_hip_set_camera_view(vrt_hip_ctx *ctx, uint32_t width, uint32_t height, const float view[16]);
 
 /* -------- options ---------------------------------------------------------------------- */
 /* exp_kind / erf_kind: the reference's template arguments.  cull_eps: Gaussians whose

@@ -70,6 +70,7 @@ SYMBOLS = {
     "vrt_hip_shard_pixels": (C.c_size_t, [_vp]),
     "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
     "vrt_hip_set_table_step": (C.c_int, [_vp, C.c_float]),
+    "vrt_hip_set_camera_view": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p]),
     "vrt_hip_frame": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, C.c_int]),
     "vrt_hip_sync": (C.c_int, [_vp]),
     "vrt_hip_assemble_shards_device": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -211,6 +212,12 @@ class Renderer:
         self.w, self.h = w, h
         self._chk(self._L.vrt_hip_set_camera(self._h, w, h, _fp(_f3(pos)), _fp(_f3(right)), _fp(_f3(up)),
                                              _fp(_f3(front)), focal), "set_camera")
+
+    def set_camera_view(self, w, h, view):
+        """In-kernel rays that are bit for bit the reference's: plane point = inverse(view) * (x, y, 0, 1)."""
+        self.w, self.h = w, h
+        v = np.ascontiguousarray(np.asarray(view, np.float32).reshape(16))
+        self._chk(self._L.vrt_hip_set_camera_view(self._h, w, h, _fp(v)), "set_camera_view")
 
     def set_options(self, exp_kind=EXP_VCL, erf_kind=ERF_AS, cull_eps=1e-9):
         self._chk(self._L.vrt_hip_set_options(self._h, exp_kind, erf_kind, cull_eps), "set_options")

@@ -102,6 +102,8 @@ struct vrt_hip_ctx {
     // rays
     uint32_t w = 0, h = 0;
     bool plane_mode = false;
+    bool view_mode = false;   // rays from inverse(view) (vrt_hip_set_camera_view)
+    float inv_view[16] = { 0 };
     bool plane_affine = false; // plane arrays are a pinhole pattern: corner rays bound a tile's cone
     DevBuf<float> xs, ys, zs;
     float cam_pos[3] = { 0, 0, 0 }, cam_right[3] = { 1, 0, 0 }, cam_up[3] = { 0, 1, 0 }, cam_front[3] = { 0, 0, -1 };
@@ -230,6 +232,9 @@ RayGen ray_gen(const vrt_hip_ctx *c, const float origin[3])
     r.focal = c->focal;
     r.inv_half_w = 1.f / (c->w / 2.f); r.inv_half_h = 1.f / (c->h / 2.f);
     r.width = c->w; r.height = c->h;
+    r.view_mode = (c->view_mode && !c->plane_mode) ? 1 : 0;
+    for (int i = 0; i < 3; ++i) { r.m0[i] = c->inv_view[i]; r.m1[i] = c->inv_view[4 + i]; r.m3[i] = c->inv_view[12 + i]; }
+    r.half_w = c->w / 2.f; r.half_h = c->h / 2.f;
     return r;
 }
 
@@ -332,7 +337,10 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     const TileLists geo = tile_geometry(c);
     const size_t nt = (size_t)geo.tiles_w * geo.tiles_h;
     // the tile cone is built from corner rays: needs pinhole rays (always true for in-kernel ray generation)
-    const bool refine = !c->plane_mode || c->plane_affine;
+    // ... and tiles that are rectangles of the image: with the reference's truncated tile size the row stride
+    // tile_w*tiles_w can differ from the width (rt.h:364-365), a tile's rows then drift sideways and wrap around the
+    // image edge, and its rays are no cone around its corner rays (found by tests/fuzz_parity.py: 33x100, 5 tiles)
+    const bool refine = (!c->plane_mode || c->plane_affine) && geo.stride == c->w;
 
     // geometry of the second level and its buffers
     uint32_t n_local = (uint32_t)nt;
@@ -869,7 +877,59 @@ int vrt_hip_set_camera(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float pos[3
         memcmp(c->cam_up, up, 12) || memcmp(c->cam_front, front, 12))
         c->reset_seq = c->frame_seq; // another camera: earlier frames' reports say nothing about the next one
     memcpy(c->cam_pos, pos, 12); memcpy(c->cam_right, right, 12); memcpy(c->cam_up, up, 12); memcpy(c->cam_front, front, 12);
-    c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->rays_set = true; c->lists_dirty = true;
+    c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->view_mode = false; c->rays_set = true; c->lists_dirty = true;
+    return VRT_HIP_OK;
+}
+
+// glm::inverse(mat4) (func_matrix.inl, compute_inverse<4, 4>: cofactor expansion), float, in glm's order of operations
+// and unfused -- the reference's projection plane is inverse(view) * point (camera.cpp:60-69), and its rays are only
+// reproduced bit for bit if the inverse is
+static void glm_inverse4(const float a[16], float out[16])
+{
+#pragma clang fp contract(off)
+#define M(c, r) a[(c) * 4 + (r)]
+    const float c00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3), c02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3),
+                c03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+    const float c04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3), c06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3),
+                c07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+    const float c08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2), c10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2),
+                c11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+    const float c12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3), c14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3),
+                c15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+    const float c16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2), c18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2),
+                c19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+    const float c20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1), c22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1),
+                c23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+    const float f0[4] = { c00, c00, c02, c03 }, f1[4] = { c04, c04, c06, c07 }, f2[4] = { c08, c08, c10, c11 };
+    const float f3[4] = { c12, c12, c14, c15 }, f4[4] = { c16, c16, c18, c19 }, f5[4] = { c20, c20, c22, c23 };
+    const float v0[4] = { M(1, 0), M(0, 0), M(0, 0), M(0, 0) }, v1[4] = { M(1, 1), M(0, 1), M(0, 1), M(0, 1) };
+    const float v2[4] = { M(1, 2), M(0, 2), M(0, 2), M(0, 2) }, v3[4] = { M(1, 3), M(0, 3), M(0, 3), M(0, 3) };
+    const float sa[4] = { +1, -1, +1, -1 }, sb[4] = { -1, +1, -1, +1 };
+    float inv[16];
+    for (int i = 0; i < 4; ++i) {
+        inv[0 * 4 + i] = (v1[i] * f0[i] - v2[i] * f1[i] + v3[i] * f2[i]) * sa[i];
+        inv[1 * 4 + i] = (v0[i] * f0[i] - v2[i] * f3[i] + v3[i] * f4[i]) * sb[i];
+        inv[2 * 4 + i] = (v0[i] * f1[i] - v1[i] * f3[i] + v3[i] * f5[i]) * sa[i];
+        inv[3 * 4 + i] = (v0[i] * f2[i] - v1[i] * f4[i] + v2[i] * f5[i]) * sb[i];
+    }
+    const float d0 = M(0, 0) * inv[0], d1 = M(0, 1) * inv[4], d2 = M(0, 2) * inv[8], d3 = M(0, 3) * inv[12];
+    const float one_over_det = 1.f / ((d0 + d1) + (d2 + d3));
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * one_over_det;
+#undef M
+}
+
+int vrt_hip_set_camera_view(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float view[16])
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!w || !h || !view) return fail(c, VRT_HIP_ERR_INVALID, "set_camera_view: bad argument");
+    float inv[16];
+    glm_inverse4(view, inv);
+    for (int i = 0; i < 16; ++i)
+        if (!std::isfinite(inv[i])) return fail(c, VRT_HIP_ERR_INVALID, "set_camera_view: the view matrix is singular");
+    if (c->w != w || c->h != h || c->plane_mode || !c->view_mode || memcmp(c->inv_view, inv, sizeof inv))
+        c->reset_seq = c->frame_seq; // another camera: earlier frames' reports say nothing about the next one
+    memcpy(c->inv_view, inv, sizeof inv);
+    c->w = w; c->h = h; c->plane_mode = false; c->view_mode = true; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
 }
 

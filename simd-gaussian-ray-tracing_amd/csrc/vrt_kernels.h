@@ -78,6 +78,11 @@ struct RayGen {
     float pos[3], right[3], up[3], front[3];
     float focal, inv_half_w, inv_half_h;
     uint32_t width, height;
+    // view mode (vrt_hip_set_camera_view): the reference's own plane points, inverse(view) * (x, y, 0, 1) with
+    // x = -1 + j / (w/2), y = -1 + i / (h/2) (camera.cpp:60-69), evaluated in glm's order -- bit-identical rays
+    int view_mode;
+    float m0[3], m1[3], m3[3];  // columns 0, 1, 3 of inverse(view) (column 2 meets the 0 of the point)
+    float half_w, half_h;
 };
 
 struct RenderTarget {

@@ -79,6 +79,11 @@ __device__ __forceinline__ float sub_ref(float a, float b)
 #pragma clang fp contract(off)
     return a - b;
 }
+__device__ __forceinline__ float add_ref(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
 __device__ __forceinline__ float mul_ref(float a, float b)
 {
 #pragma clang fp contract(off)
@@ -320,6 +325,14 @@ __device__ __forceinline__ LaneRay pixel_ray(const RayGen &R, uint64_t pix)
     float px, py, pz;
     if (R.xs) {
         px = R.xs[pix]; py = R.ys[pix]; pz = R.zs[pix];
+    } else if (R.view_mode) {
+        // camera.cpp:60-69 with glm's mat4 * vec4: (m0 x + m1 y) + (m2 0 + m3 1), unfused -- the reference's plane point
+        uint32_t jcol, irow;
+        col_row(R, pix, jcol, irow);
+        const float x = add_ref(-1.f, (float)jcol / R.half_w), y = add_ref(-1.f, (float)irow / R.half_h);
+        px = add_ref(add_ref(mul_ref(R.m0[0], x), mul_ref(R.m1[0], y)), R.m3[0]);
+        py = add_ref(add_ref(mul_ref(R.m0[1], x), mul_ref(R.m1[1], y)), R.m3[1]);
+        pz = add_ref(add_ref(mul_ref(R.m0[2], x), mul_ref(R.m1[2], y)), R.m3[2]);
     } else {
         // closed form of camera.cpp:52,60-69: plane = pos + x right + y up - focal front
         uint32_t jcol, irow;
@@ -375,6 +388,13 @@ __device__ __forceinline__ LaneRay cone_ray(const RayGen &R, uint64_t pix)
     float px, py, pz;
     if (R.xs) {
         px = R.xs[pix]; py = R.ys[pix]; pz = R.zs[pix];
+    } else if (R.view_mode) {
+        uint32_t jcol, irow;
+        col_row(R, pix, jcol, irow);
+        const float x = -1.f + (float)jcol * R.inv_half_w, y = -1.f + (float)irow * R.inv_half_h;
+        px = R.m0[0] * x + R.m1[0] * y + R.m3[0];
+        py = R.m0[1] * x + R.m1[1] * y + R.m3[1];
+        pz = R.m0[2] * x + R.m1[2] * y + R.m3[2];
     } else {
         uint32_t jcol, irow;
         col_row(R, pix, jcol, irow);

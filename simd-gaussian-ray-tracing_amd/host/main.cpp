@@ -168,8 +168,7 @@ int main(int argc, char **argv)
             chk(vrt_hip_set_plane(ctx, (u32)width, (u32)height, cam.projection_plane.xs.data(), cam.projection_plane.ys.data(),
                                   cam.projection_plane.zs.data()), "set_plane");
         else
-            chk(vrt_hip_set_camera(ctx, (u32)width, (u32)height, cam.position.data(), cam.right.data(), cam.up.data(),
-                                   cam.front.data(), cam.focal_length), "set_camera");
+            chk(vrt_hip_set_camera_view(ctx, (u32)width, (u32)height, cam.view_matrix.data()), "set_camera_view");
 
         // Tiled modes: tile_gaussians + render in one call on the context's stream.  A frame whose image is needed on
         // the host (PNG) or whose time is printed is waited for; the frames of an animation that only reports its

@@ -129,6 +129,25 @@ def test_camera_basis_mode_matches_plane_mode(pkg, oracle, renderer):
         assert np.abs(rad_p - rad_c).max() <= 2e-5
 
 
+def test_view_mode_rays_are_the_reference_rays(pkg, oracle, renderer):
+    """vrt_hip_set_camera_view: in-kernel rays from inverse(view), evaluated like camera.cpp:60-69 with glm's arithmetic.
+    Given the same view matrix they are bit for bit the rays of the plane arrays, so the images are IDENTICAL -- also
+    where the closed-form basis mode drifts (small sigma far from the camera: |oc|^2 - mubar^2 amplifies the last bit of
+    a ray direction)."""
+    rng = np.random.default_rng(3)
+    n = 400
+    g = oracle.gaussians(rng.uniform(0, 1, size=(n, 4)), rng.normal(size=(n, 3)) * 0.6, rng.uniform(0.03, 0.1, n), rng.uniform(0.2, 2.0, n))
+    for (w, h, rot, tiles_n) in [(96, 64, 33.0, 4), (128, 128, 210.0, 16), (100, 60, 0.0, 0)]:
+        cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h, tiles_n=tiles_n, rot=rot)
+        renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+        img_p, rad_p = renderer.render(origin)
+        renderer.set_camera_view(w, h, oracle.camera_view(cam))
+        img_v, rad_v = renderer.render(origin)
+        assert rad_p.max() > 0.05
+        np.testing.assert_array_equal(rad_v, rad_p)
+        np.testing.assert_array_equal(img_v, img_p)
+
+
 def test_transmittance_three_gaussians(pkg, oracle, renderer):
     """Scene and sweep of the reference's tests/transmittance.cpp:9-31."""
     g = oracle.gaussians([[0, 1, 0, .1], [0, 0, 1, .7], [1, 0, 0, 1]], [[.3, .3, .5], [-.3, -.3, 0], [0, 0, 2]],
@@ -338,10 +357,11 @@ def test_erf_saturation_thresholds(pkg, renderer):
     assert renderer.eval_erf(pkg.ERF_AS, np.array([5.3], np.float32))[0] < 1.0
 
 
-@pytest.mark.parametrize("w,h,tiles_n", [(100, 100, 5), (96, 64, 3), (100, 100, 16), (72, 40, 2)])
+@pytest.mark.parametrize("w,h,tiles_n", [(100, 100, 5), (96, 64, 3), (100, 100, 16), (72, 40, 2), (33, 100, 5), (64, 256, 5)])
 def test_ragged_geometry(pkg, oracle, renderer, w, h, tiles_n):
     """Tile sizes that are not multiples of 8 or 32, non-square images, and the reference's truncated tile size
-    (rt.h:348-349) with its row stride tile_w*tiles_w != width (rt.h:364-365): same pixels, same values."""
+    (rt.h:348-349) with its row stride tile_w*tiles_w != width (rt.h:364-365): same pixels, same values.  In the last
+    two the stride differs so much that a tile's rows wrap around the image edge several times."""
     g = oracle.grid_scene(6)
     cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h, tiles_n=tiles_n)
     renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)

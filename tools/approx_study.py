@@ -39,7 +39,7 @@ for name, k in EXP.items():
 
 def frames(g, w, ek, rk, reps):
     cam, _ = scene.cli_camera(w, w)
-    r.set_gaussians(scene.grid_scene(g)); r.set_camera(w, w, cam.position, cam.right, cam.up, cam.front, 1.0)
+    r.set_gaussians(scene.grid_scene(g)); r.set_camera_view(w, w, cam.view)
     r.set_options(ek, rk, 1e-9)
     r.tile_gaussians(2 / 16, 2 / 16, cam.view)
     pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED

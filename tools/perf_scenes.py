@@ -8,7 +8,7 @@ import torch
 r = pkg.Renderer(0)
 def run(name, g, w, eps=1e-9, reps=5):
     cam, _ = scene.cli_camera(w, w)
-    r.set_gaussians(g); r.set_camera(w, w, cam.position, cam.right, cam.up, cam.front, 1.0)
+    r.set_gaussians(g); r.set_camera_view(w, w, cam.view)
     r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps)
     r.tile_gaussians(2/16, 2/16, cam.view)
     r.enable_stats(True)

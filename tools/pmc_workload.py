@@ -10,7 +10,7 @@ from sgrt_amd import scene
 w = 2048
 r = pkg.Renderer(0)
 cam, _ = scene.cli_camera(w, w)
-r.set_camera(w, w, cam.position, cam.right, cam.up, cam.front, 1.0)
+r.set_camera_view(w, w, cam.view)
 img = torch.zeros(w * w, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED

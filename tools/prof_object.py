@@ -11,7 +11,7 @@ step = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 r = pkg.Renderer(0)
 r.set_gaussians(scene.read_obj(os.path.join(GOLDEN, "test-objects", name + ".obj")))
 cam, _ = scene.cli_camera(w, w)
-r.set_camera(w, w, cam.position, cam.right, cam.up, cam.front, 1.0)
+r.set_camera_view(w, w, cam.view)
 r.set_table_step(step)
 out = torch.zeros(w * w, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
