@@ -408,7 +408,14 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     }
     if (fuse) {
         a.next_zero8 = other_set; // cleared for the next generation by workgroup 0
-        launch_build_tile_lists(a, f, !device_bin, fuse ? n_local : (uint32_t)nt, st);
+        if (n_local) {
+            launch_build_tile_lists(a, f, !device_bin, n_local, st);
+        } else {
+            // a rank that owns no tile (more ranks than tiles) launches no list kernel: nobody adds to this generation's
+            // counters and nobody clears the next one's -- do both here, or the next render would add to stale counts
+            // (found by tests/fuzz_parity.py: 4 tiles on 5 and 8 ranks)
+            HIPCHK(c, hipMemsetAsync(c->c_counters.p, 0, 16 * sizeof(uint32_t), st));
+        }
         if (target) target->cleared = 1;
     } else {
         if (!c->work_is_ref) launch_build_tile_lists(a, f, !device_bin, (uint32_t)nt, st);

@@ -57,11 +57,37 @@ for case in range(ncase):
         r.set_camera_view(w, h, view)
         _, rad_b = r.render(origin)
         errb = np.abs(rad_b - rad).max()
+    # (c) every third case: caller-made tiles (vrt_hip_set_tiles) and tile shards of a random world size, assembled:
+    #     all must reproduce the image bit for bit
+    extra = ""
+    if tiles_n and case % 3 == 0:
+        import torch
+        r.set_plane(w, h, *plane); r.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, view)
+        r.set_tiles(tiles)
+        img_h, _ = r.render(origin, want_radiance=False)
+        r.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, view)
+        world = int(rng.choice([2, 3, 5, 8]))
+        st = torch.cuda.current_stream().cuda_stream
+        shards = []
+        for rank in range(world):
+            r.set_shard(rank, world)
+            buf = torch.zeros(max(r.shard_pixels(), 1), dtype=torch.int32, device="cuda")
+            r.render_shard_device(origin, pkg.PACK_ROUND | pkg.ALPHA_COMPUTED, buf.data_ptr(), st)
+            torch.cuda.synchronize()
+            shards.append(buf)
+        out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        r.assemble_shards_device(torch.cat(shards).data_ptr(), out.data_ptr(), st)
+        torch.cuda.synchronize()
+        r.set_shard(0, 1)
+        ok_h = bool((img_h == img).all()); ok_s = bool((out.cpu().numpy().view(np.uint32).reshape(h, w) == img).all())
+        extra = f"  host tiles {'==' if ok_h else '!='}  shards x{world} {'==' if ok_s else '!='}"
+        if not (ok_h and ok_s):
+            errb = max(errb, 1.0)
     worst = max(worst, err)
     flag = "  <-- FAIL" if (err > 1e-4 or errt > 1e-4 or errb != 0.0) else ""
     if flag and os.environ.get("VRT_FUZZ_DUMP"):   # keep the case for a float64 post-mortem
         np.savez(os.path.join(os.environ["VRT_FUZZ_DUMP"], f"fuzz_case_{case}.npz"), g=g, xs=plane[0], ys=plane[1], zs=plane[2],
                  origin=origin, pix=pix, gpu=rad.reshape(-1, 4)[pix], oracle=orad, w=w, h=h, tiles_n=tiles_n, view=view,
                  offsets=tiles["offsets"] if tiles else np.zeros(0), indices=tiles["indices"] if tiles else np.zeros(0))
-    print(f"case {case}: n={n} {w}x{h} tiles={tiles_n} sigma=[{sig_lo},{sig_hi}] eps={eps:g} peak={rad.max():.3f}: vs oracle {err:.2e}  table vs exact {errt:.2e}  view-mode rays vs plane arrays {errb:.2e}{flag}", flush=True)
+    print(f"case {case}: n={n} {w}x{h} tiles={tiles_n} sigma=[{sig_lo},{sig_hi}] eps={eps:g} peak={rad.max():.3f}: vs oracle {err:.2e}  table vs exact {errt:.2e}  view-mode rays vs plane arrays {errb:.2e}{extra}{flag}", flush=True)
 print("worst vs oracle", worst)

@@ -620,3 +620,35 @@ def test_table_mode_stays_inside_the_tolerance(pkg, oracle, renderer, name, step
         np.testing.assert_array_equal(rad2, exact)
     finally:
         renderer.set_table_step(0.0)
+
+
+def test_more_ranks_than_tiles(pkg, oracle, renderer):
+    """4 tiles on 5 and 8 'ranks' (one context playing every rank in turn): ranks without a tile render nothing, launch no
+    list kernel, and must leave the queue counters as the next render expects them (tests/fuzz_parity.py found that they
+    did not); the assembled frame and the full-frame render that follows are the single-rank image."""
+    import torch
+    w, h = 96, 64
+    g = oracle.grid_scene(6)
+    cam, plane, origin, tiles = setup_scene(pkg, oracle, renderer, g, w, h, tiles_n=2)
+    renderer.set_shard(0, 1)
+    full, full_rad = renderer.render(origin)
+    assert (full >> 24).max() > 0
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    st = torch.cuda.current_stream().cuda_stream
+    for world in (5, 8):
+        shards = []
+        for rank in range(world):
+            renderer.set_shard(rank, world)
+            buf = torch.zeros(renderer.shard_pixels(), dtype=torch.int32, device="cuda")
+            renderer.render_shard_device(origin, pack, buf.data_ptr(), st)
+            torch.cuda.synchronize()
+            shards.append(buf)
+        assert len({b.numel() for b in shards}) == 1          # one fixed-size gather moves the frame
+        out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        renderer.assemble_shards_device(torch.cat(shards).data_ptr(), out.data_ptr(), st)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full)
+        renderer.set_shard(0, 1)
+        again, again_rad = renderer.render(origin)
+        np.testing.assert_array_equal(again, full)
+        np.testing.assert_array_equal(again_rad, full_rad)
