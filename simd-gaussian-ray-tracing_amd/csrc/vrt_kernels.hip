@@ -1575,18 +1575,19 @@ __global__ void transmittance_kernel(SceneTables S, float ox, float oy, float oz
     if (k >= ns) return;
     const float s = s_in[k];
     float T = 0.f;
-    for (uint32_t q = 0; q < S.n; ++q) { // rt.h:36-52, same operation order
+    for (uint32_t q = 0; q < S.n; ++q) { // rt.h:36-52, same operations in the same order, unfused (see dot3_ref)
         const float4 g = S.mu_sig[q];
         const float mag = S.gD[q].z;
-        const float cx = g.x - ox, cy = g.y - oy, cz = g.z - oz;
-        const float mu_bar = cx * nx + cy * ny + cz * nz;
-        const float oc_sq = cx * cx + cy * cy + cz * cz;
-        const float inv_2_sigma2 = 1.f / (2.f * g.w * g.w);
-        const float c_bar = mag * vexp<EXP>(-((oc_sq - mu_bar * mu_bar) * inv_2_sigma2));
-        const float sqrt_2_sig = SQRT_2 * g.w;
+        const float cx = sub_ref(g.x, ox), cy = sub_ref(g.y, oy), cz = sub_ref(g.z, oz);
+        const float mu_bar = dot3_ref(cx, cy, cz, nx, ny, nz);
+        const float oc_sq = dot3_ref(cx, cy, cz, cx, cy, cz);
+        const float inv_2_sigma2 = 1.f / mul_ref(mul_ref(2.f, g.w), g.w);
+        const float c_bar = mul_ref(mag, vexp<EXP>(-mul_ref(sub_ref(oc_sq, mul_ref(mu_bar, mu_bar)), inv_2_sigma2)));
+        const float sqrt_2_sig = mul_ref(SQRT_2, g.w);
         const float mu_bar_n = mu_bar / sqrt_2_sig;
         const float s_n = s / sqrt_2_sig;
-        T += g.w * c_bar * INV_SQRT_2_PI * (verf<ERF>(-mu_bar_n) - verf<ERF>(s_n - mu_bar_n));
+        const float term = mul_ref(mul_ref(mul_ref(g.w, c_bar), INV_SQRT_2_PI), sub_ref(verf<ERF>(-mu_bar_n), verf<ERF>(sub_ref(s_n, mu_bar_n))));
+        T = add_ref(T, term);
     }
     T_out[k] = vexp<EXP>(T);
 }

@@ -83,6 +83,25 @@ for case in range(ncase):
         extra = f"  host tiles {'==' if ok_h else '!='}  shards x{world} {'==' if ok_s else '!='}"
         if not (ok_h and ok_s):
             errb = max(errb, 1.0)
+    # (d) every fourth case: the point queries against the oracle (rt.h:32-54, 146-223; rt.cpp:8-27)
+    if case % 4 == 1 and n <= 600:
+        ek, rk = [(pkg.EXP_VCL, pkg.ERF_AS), (pkg.EXP_LIBM, pkg.ERF_LIBM), (pkg.EXP_LIBM, pkg.ERF_AS)][case % 3]
+        r.set_options(ek, rk, eps)
+        o3 = origin + rng.normal(size=3).astype(np.float32) * 0.1
+        d3 = rng.normal(size=(5, 3)).astype(np.float32) * 0.2 + (np.zeros(3, np.float32) - o3)
+        d3 /= np.linalg.norm(d3, axis=1, keepdims=True).astype(np.float32)
+        got_r = r.radiance(np.repeat(o3[None], 5, 0), d3)
+        want_r = np.stack([O.radiance(o3, d, g, ek, rk) for d in d3])
+        s_ = np.linspace(0.0, 8.0, 9).astype(np.float32)
+        got_t = r.transmittance(o3, d3[0], s_)
+        want_t = O.transmittance(o3, d3[0], s_, g, ek, rk)
+        pts = rng.normal(size=(7, 3)).astype(np.float32)
+        got_d = r.density(pts); want_d = np.array([O.density(p_, g) for p_ in pts], np.float32)
+        eq = max(np.abs(got_r - want_r).max(), np.abs(got_t - want_t).max(), np.abs(got_d - want_d).max() / max(1.0, float(np.abs(want_d).max())))
+        extra += f"  point queries {eq:.1e} (radiance {np.abs(got_r - want_r).max():.1e} T {np.abs(got_t - want_t).max():.1e} density {np.abs(got_d - want_d).max():.1e} variant {ek},{rk})"
+        if eq > 1e-4:
+            errb = max(errb, 1.0)
+        r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps)
     worst = max(worst, err)
     flag = "  <-- FAIL" if (err > 1e-4 or errt > 1e-4 or errb != 0.0) else ""
     if flag and os.environ.get("VRT_FUZZ_DUMP"):   # keep the case for a float64 post-mortem
