@@ -57,6 +57,18 @@ for case in range(ncase):
         r.set_camera_view(w, h, view)
         _, rad_b = r.render(origin)
         errb = np.abs(rad_b - rad).max()
+    # (b2) the packed image is the packed radiance, pixel for pixel (rt.h:373-377), in all four packing conventions
+    def pack_np(rad4, flags):
+        c = np.minimum(rad4.astype(np.float32), np.float32(1.0)) * np.float32(255.0)
+        q = np.rint(c[..., :3]).astype(np.uint32) if flags & pkg.PACK_ROUND else c[..., :3].astype(np.uint32)
+        a = (np.rint(c[..., 3]).astype(np.uint32) << 24) if flags & pkg.ALPHA_COMPUTED else np.uint32(0xFF000000)
+        return a | (q[..., 0] << 16) | (q[..., 1] << 8) | q[..., 2]
+    flags = int(rng.choice([pkg.PACK_ROUND | pkg.ALPHA_COMPUTED, pkg.PACK_ROUND | pkg.ALPHA_OPAQUE, pkg.PACK_TRUNC | pkg.ALPHA_OPAQUE, pkg.PACK_TRUNC | pkg.ALPHA_COMPUTED]))
+    r.set_plane(w, h, *plane)
+    img_f, rad_f = r.render(origin, flags)
+    covered = img_f != 0 if tiles_n else np.ones_like(img_f, bool)      # pixels outside a ragged tile grid stay 0
+    if not bool((pack_np(rad_f, flags)[covered] == img_f[covered]).all()) or not bool((rad_f == rad).all()):
+        errb = max(errb, 1.0); print("   packing mismatch, flags", flags)
     # (c) every third case: caller-made tiles (vrt_hip_set_tiles) and tile shards of a random world size, assembled:
     #     all must reproduce the image bit for bit
     extra = ""
