@@ -275,7 +275,7 @@ def main():
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
         traffic, traffic_frame, valu = None, None, None
         try:    # PMC passes are separate runs (profiles/README.md); their committed summary supplies `traffic`
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")))
             if world == 1 and args.grid == 64 and w == 2048 and not args.plane_arrays:
                 traffic = pmc["render_kernel_traffic_bytes_per_launch"]["lower"]
                 traffic_frame = pmc["frame_hbm_bytes"]["write"] + pmc["frame_hbm_bytes"]["fetch_raw"]
@@ -285,7 +285,7 @@ def main():
                     rate = nv / (kernel_ms * 1e-3)
                     frame_rate = (nv + nl) / (ms_per_step * 1e-3)   # all VALU work of a frame over the frame time
                     valu = {"wave_instructions_per_launch": nv, "achieved_per_s": rate, "peak_per_s": VALU_PEAK_WAVE_INSTR,
-                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01c_pmc_traffic.json (SQ_INSTS_VALU)",
+                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01d_pmc_traffic.json (SQ_INSTS_VALU)",
                             "frame": {"wave_instructions": nv + nl, "achieved_per_s": frame_rate, "frac": frame_rate / VALU_PEAK_WAVE_INSTR}}
         except (OSError, KeyError, ValueError):
             pass
