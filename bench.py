@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--gather-frames", type=int, default=16, help="N > 1: frames per RCCL gather (one collective per batch)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial frames")
+    ap.add_argument("--parallel", choices=["tiles", "frames"], default="tiles",
+                    help="N > 1: 'tiles' = one frame's tiles sharded over the ranks + gather (the headline, SURVEY 8e); 'frames' = "
+                         "every rank renders whole frames of its own, no collective (the replicas-only alternative: weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plane-arrays", action="store_true", help="feed reference-style plane arrays (12 B/ray reads)")
     args = ap.parse_args()
@@ -142,7 +145,8 @@ def main():
     # double-buffered frame loop of any renderer.  Every frame does all of its work; the strictly serial figures are
     # measured after the timed region and reported next to the headline ("serial").  N > 1: one context per rank
     # (the frame rate is set by the gather there).
-    nctx = max(1, args.frames_in_flight) if world == 1 else 1
+    solo = world == 1 or args.parallel == "frames"   # this rank renders whole frames on its own
+    nctx = max(1, args.frames_in_flight) if solo else 1
 
     def make_renderer():
         r_ = pkg.Renderer(local_rank)
@@ -152,7 +156,7 @@ def main():
         else:
             r_.set_camera_view(w, h, view)   # in-kernel rays = the reference's plane points, bit for bit (camera.cpp:60-69)
         r_.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
-        r_.set_shard(rank, world)
+        r_.set_shard(*((0, 1) if solo else (rank, world)))
         return r_
 
     ctxs = [make_renderer() for _ in range(nctx)]
@@ -166,7 +170,7 @@ def main():
 
     images = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(nctx)]
     image = images[0]
-    frames = [r_.frame_call(tw, th, view, origin, pack, shard=world > 1) for r_ in ctxs]   # tile_gaussians + render, one C call
+    frames = [r_.frame_call(tw, th, view, origin, pack, shard=not solo) for r_ in ctxs]   # tile_gaussians + render, one C call
     frame = frames[0]
     img_ptrs = [im.data_ptr() for im in images]
     img_ptr = img_ptrs[0]
@@ -174,7 +178,7 @@ def main():
     # gather per F frames moves them to rank 0 (double-buffered against the next batch's rendering), rank 0 assembles
     # every gathered frame into raster order.  The same class runs under gloo in tests/test_dist_gloo.py.
     F = max(1, min(args.gather_frames, max(args.steps, 1)))
-    if world > 1:
+    if not solo:
         from sgrt_amd.sharding import FrameGatherer
         npx = r.shard_pixels()
         fg = FrameGatherer(dist, rank, world, npx, F, "cuda", stage=backend != "nccl")
@@ -188,7 +192,7 @@ def main():
             r.assemble_shards_device(gath_ptr[b] + 4 * f * npx, img_ptr, sp, rank_stride_px=F * npx)
 
     def run(nsteps, in_flight=nctx):
-        if world == 1:
+        if solo:
             for k in range(nsteps):
                 i = k % in_flight
                 frames[i](img_ptrs[i], sps[i])
@@ -248,7 +252,7 @@ def main():
     kernel_ms = float(kern_ms.item())
 
     if rank == 0:
-        rays = w * h * args.steps
+        rays = w * h * args.steps * (world if (solo and world > 1) else 1)   # frames mode: every rank renders K whole frames
         ms_per_step = elapsed / args.steps * 1e3
         # ---- statistics pass (outside the timed region): list lengths, shaded blocks ----
         counts = r.tile_counts()
@@ -260,18 +264,19 @@ def main():
         frame_ok = all(bool((im.cpu().numpy().view(np.uint32) == _img.reshape(-1)).all()) for im in images)
         st = r.stats()
         r.enable_stats(False)
-        r.set_shard(rank, world)
+        r.set_shard(*((0, 1) if solo else (rank, world)))
         sb = max(st["shaded_blocks"], 1)
         # ---- roofline.  Algorithmic HBM bytes: 4 B per ray written (+12 B per ray
         # read with --plane-arrays), the Gaussian rows once (64 B each), the candidate lists once (4 B per entry).
         # Dominant kernel = render_kernel: it writes the rays it shades and reads their cells' lists; the other rays
         # of the frame are cleared by the list kernel, so the FRAME figure is given next to it.
         per_ray = 4 + (12 if args.plane_arrays else 0)
-        render_bytes = (sb * 64 * per_ray + 4 * st["tile_entries"] + 64 * len(g)) / world
-        frame_bytes = (w * h * per_ray + 64 * len(g) + 4 * n_entries) / world
+        share = 1 if solo else world   # tile sharding: a rank's kernels see 1/world of the frame
+        render_bytes = (sb * 64 * per_ray + 4 * st["tile_entries"] + 64 * len(g)) / share
+        frame_bytes = (w * h * per_ray + 64 * len(g) + 4 * n_entries) / share
         render_gbs = render_bytes / (kernel_ms * 1e-3) / 1e9
         # the whole frame: wall time per step of the timed region (one rank: nothing but the launch sequence is in it)
-        frame_ms = ms_per_step if world == 1 else kt["lists_ms"] + kt["render_ms"] + kt["dense_ms"]
+        frame_ms = ms_per_step if solo else kt["lists_ms"] + kt["render_ms"] + kt["dense_ms"]
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
         traffic, traffic_frame, valu = None, None, None
         try:    # PMC passes are separate runs (profiles/README.md); their committed summary supplies `traffic`
@@ -292,11 +297,12 @@ def main():
         result = {
             "metric": "Mrays/sec (whole node), 2048^2 image, 64x64 Gaussian grid", "value": rays / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (solo and world > 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"-g {args.grid} -w {w} (tiles {args.tiles}, mode-8 packing, cull_eps {args.cull_eps:g}, "
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
                        "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
-                       "parallelism": f"tile-shard x{world}" + (f" + RCCL gather to rank 0 every {F} frames" if world > 1 else ""),
+                       "parallelism": (f"whole frames on each of {world} ranks, no collective" if (solo and world > 1) else
+                                       f"tile-shard x{world}" + (f" + RCCL gather to rank 0 every {F} frames" if world > 1 else "")),
                        "frames_in_flight": nctx,
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
