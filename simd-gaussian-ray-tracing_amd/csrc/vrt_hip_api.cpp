@@ -76,7 +76,8 @@ struct vrt_hip_ctx {
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
-    int render_waves_per_cu = 12; // persistent one-wave workgroups per CU (LDS allows 13); VRT_HIP_RENDER_WAVES overrides
+    int render_waves_per_cu = 13; // persistent one-wave workgroups per CU: what LDS allows (VGPRs: three per SIMD run at a time; the
+                                  // 13th starts when the first retires); VRT_HIP_RENDER_WAVES overrides
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
     int lists_for_shard = -1; // sharding mode the cell lists were built for
     bool lists_fresh = false; // the queue counters were zeroed by the list build of this very call
