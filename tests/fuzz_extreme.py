@@ -1,0 +1,52 @@
+"""Extreme-value cross-check against the oracle, run by hand on an MI355X (python tests/fuzz_extreme.py [seed] [cases]):
+optically thick media (magnitude up to 50), sigma 1e-3 .. 3, Gaussians behind the camera and on the image plane, negative and
+zero magnitudes, albedo > 1.  Round 1: 80 cases, worst relative deviation 1.8e-6, packed pixels within one step."""
+import sys, os
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import numpy as np
+from conftest import load_pkg
+pkg = load_pkg()
+import oracle as O
+O.build()
+r = pkg.Renderer(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+worst = 0
+for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    n = int(rng.choice([2, 10, 60, 300]))
+    w, h = int(rng.choice([48, 64, 96])), int(rng.choice([48, 64]))
+    tiles_n = int(rng.choice([0, 2, 4, 16]))
+    kind = rng.choice(["thick", "tiny_sigma", "huge_sigma", "behind", "negmag", "bright", "zero_mag", "near_plane"])
+    mu = rng.normal(size=(n, 3)) * 0.6 + np.array([0, 0, 1.0])
+    sig = rng.uniform(0.03, 0.3, n); mag = rng.uniform(0.1, 1.0, n); alb = rng.uniform(0, 1, size=(n, 4))
+    if kind == "thick": mag = rng.uniform(5, 50, n)
+    if kind == "tiny_sigma": sig = rng.uniform(1e-3, 5e-3, n); mag = rng.uniform(1, 20, n)
+    if kind == "huge_sigma": sig = rng.uniform(1.0, 3.0, n); mag = rng.uniform(0.01, 0.2, n)
+    if kind == "behind": mu[:, 2] -= rng.uniform(3, 8, n) * (rng.random(n) < 0.5)
+    if kind == "negmag": mag = mag * np.where(rng.random(n) < 0.3, -1.0, 1.0)
+    if kind == "bright": alb = rng.uniform(0.5, 4.0, size=(n, 4))
+    if kind == "zero_mag": mag = mag * (rng.random(n) < 0.5)
+    if kind == "near_plane": mu[:, 2] = rng.uniform(-3.2, -2.8, n); sig = rng.uniform(0.02, 0.1, n)
+    g = O.gaussians(alb, mu, sig, mag)
+    cam, _ = O.cli_camera(w, h, initial_rot=float(rng.choice([0.0, 30.0, 180.0])))
+    plane = O.camera_plane(cam); view = O.camera_view(cam); origin = np.array(cam.position[:], np.float32)
+    eps = float(rng.choice([1e-9, 0.0]))
+    r.set_gaussians(g); r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps); r.set_plane(w, h, *plane); r.set_table_step(0.0)
+    if tiles_n: r.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, view); tiles = O.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, g, view)
+    else: r.clear_tiles(); tiles = None
+    img, rad = r.render(origin)
+    pix = np.arange(0, w * h, max(1, (w * h) // 97), dtype=np.uint32)
+    if tiles_n:
+        tw_, th_ = int(np.float32(w) * np.float32(2.0 / tiles_n) / np.float32(2.0)), int(np.float32(h) * np.float32(2.0 / tiles_n) / np.float32(2.0))
+        pix = pix[pix < min(w * h, tw_ * tiles_n * th_ * tiles_n)]
+    oimg, orad = O.render(w, h, plane, origin, g, tiles, pixels=pix)
+    got = rad.reshape(-1, 4)[pix]
+    fin = np.isfinite(orad).all(1)
+    both_nan = (~np.isfinite(got)) == (~np.isfinite(orad))
+    scale = max(1.0, float(np.abs(orad[fin]).max()) if fin.any() else 1.0)
+    err = float(np.abs(got[fin] - orad[fin]).max() / scale) if fin.any() else 0.0
+    pxd = int(np.abs(((img.reshape(-1)[pix][:, None] >> np.array([16, 8, 0, 24])) & 255).astype(int) - ((oimg[pix][:, None] >> np.array([16, 8, 0, 24])) & 255).astype(int)).max())
+    worst = max(worst, err)
+    flag = "  <-- FAIL" if (err > 1e-4 or not both_nan.all() or pxd > 1) else ""
+    print(f"case {case}: {kind:10s} n={n} {w}x{h} tiles={tiles_n} eps={eps:g} peak={np.nanmax(orad):.3g} nonfinite {int((~fin).sum())}: rel err {err:.2e} u8 diff {pxd}{flag}", flush=True)
+print("worst", worst)
