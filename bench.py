@@ -38,13 +38,65 @@ def load_pkg():
 
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_WAVE_INSTR = 1024 / 1.24e-9   # measured on MI355X (tools/ubench/valu.hip): one v_fma_f32 wave-instruction
-                                        # per 1.24 ns per SIMD with >= 2 waves/SIMD, 1024 SIMDs (= 5.3e13 lane-ops/s)
+# fp32 VALU issue peak (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on its SIMD; 256 CUs x 4
+# SIMDs; 2.4 GHz max clock) = 1.2288e12 wave-instructions/s = the 157.3 TFLOP/s vector figure / (64 lanes x 2 flop).
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2
+# What a pure v_fma_f32 loop sustains on this part, with the in-kernel clock that explains it (tools/ubench/valu.hip,
+# profiles/r02_valu_ubench.txt): the same 2 cycles per instruction at the clock the chip holds under a VALU-saturating
+# load, which is below 2.4 GHz (guide, "DVFS give-back").  Reported next to the spec figure, never instead of it.
+VALU_MEASURED_FILE = os.path.join(ROOT, "profiles", "r02_valu_ubench.json")
+
+
+def kernel_source_sha():
+    """Identity of the kernel sources a profile was taken with (tools/pmc_traffic.py stores it in its summary)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("vrt_kernels.hip", "vrt_kernels.h", "vrt_device_math.h"):
+        with open(os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def latest_pmc_summary():
+    """(path, dict) of the newest profiles/r*_pmc_traffic.json, or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    for path in reversed(files):
+        try:
+            return os.path.relpath(path, ROOT), json.load(open(path))
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def host_threads():
+    """Hardware threads this process may really use: the affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
-    """The reference CPU path stand-in (oracle/vrt_cpu_simd.*: own SIMD port of mode 8) on a bounded sample:
-    16 tiles on the tile-grid diagonal, first rows of each; scaled to whole-frame rays by inner-term count."""
+    """The reference CPU path stand-in (oracle/vrt_cpu_simd.*: own SIMD port of mode 8, one task per image tile on a
+    thread pool like rt.h:355-386) on a bounded sample: the first rows of EVERY tile -- 256 tasks, so every hardware
+    thread has work -- scaled to the whole frame by inner-term count.  `cores` = threads started; `busy_threads` =
+    process CPU time / wall time of the sample, i.e. how many of them really ran."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
@@ -56,28 +108,30 @@ def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
     nt = np.diff(tiles["offsets"]).astype(np.float64)
     tile_px = (w // tiles_n) * (h // tiles_n)
     frame_terms = float((nt ** 2).sum() * 5 * tile_px)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
-    subset = np.arange(0, tiles_n * tiles_n, tiles_n + 1, dtype=np.uint32)   # the diagonal: corners + interior
+    ntiles = tiles_n * tiles_n
+    threads = max(1, min(host_threads(), ntiles))
+    subset = np.arange(ntiles, dtype=np.uint32)
     tile_w = w // tiles_n
-    # calibrate on one row of each sampled tile, then size the sample for ~15 s
-    t0 = time.perf_counter()
-    _, terms, simd = O.simd_render_tiled(w, h, plane, cam.position[:], og, tiles, subset, cores, max_rows=1)
-    dt = time.perf_counter() - t0
-    rows = int(max(1, min(h // tiles_n, round(12.0 / max(dt, 1e-3)))))
-    t0 = time.perf_counter()
-    _, terms, simd = O.simd_render_tiled(w, h, plane, cam.position[:], og, tiles, subset, cores, max_rows=rows)
-    dt = time.perf_counter() - t0
-    sample_rays = len(subset) * rows * tile_w
+
+    def sample(rows):
+        c0, t0 = time.process_time(), time.perf_counter()
+        _, terms, simd = O.simd_render_tiled(w, h, plane, cam.position[:], og, tiles, subset, threads, max_rows=rows)
+        return terms, simd, time.perf_counter() - t0, time.process_time() - c0
+
+    # calibrate on one pixel row of each tile, then size the sample for ~15 s of wall time
+    terms, simd, dt, _ = sample(1)
+    rows = int(max(1, min(h // tiles_n, round(15.0 / max(dt, 1e-3)))))
+    terms, simd, dt, cpu_s = sample(rows)
+    sample_rays = ntiles * rows * tile_w
     terms_per_s = terms / dt
     frame_s = frame_terms / terms_per_s
     return {
-        "value": (w * h) / frame_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": (f"{len(subset)} diagonal tiles x first {rows} pixel rows = {sample_rays} rays, {terms:.3e} "
-                   f"(ray,i,k,j) inner terms in {dt:.2f} s ({terms_per_s:.3e} terms/s, SIMD width {simd}); frame = "
-                   f"{frame_terms:.3e} terms -> {frame_s:.1f} s/frame extrapolated by term count{budget_note}"),
+        "value": (w * h) / frame_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "busy_threads": cpu_s / dt, "terms_per_s_per_busy_thread": terms / max(cpu_s, 1e-9),
+        "sample": (f"all {ntiles} tiles x first {rows} pixel row(s) = {sample_rays} rays on {threads} threads "
+                   f"({cpu_s / dt:.1f} busy on average), {terms:.3e} (ray,i,k,j) inner terms in {dt:.2f} s "
+                   f"({terms_per_s:.3e} terms/s, SIMD width {simd}); frame = {frame_terms:.3e} terms -> "
+                   f"{frame_s:.1f} s/frame extrapolated by term count{budget_note}"),
         "ms_per_frame_extrapolated": frame_s * 1e3,
     }
 
@@ -278,25 +332,57 @@ def main():
         # the whole frame: wall time per step of the timed region (one rank: nothing but the launch sequence is in it)
         frame_ms = ms_per_step if solo else kt["lists_ms"] + kt["render_ms"] + kt["dense_ms"]
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
-        traffic, traffic_frame, valu = None, None, None
-        try:    # PMC passes are separate runs (profiles/README.md); their committed summary supplies `traffic`
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")))
-            if world == 1 and args.grid == 64 and w == 2048 and not args.plane_arrays:
-                traffic = pmc["render_kernel_traffic_bytes_per_launch"]["lower"]
-                traffic_frame = pmc["frame_hbm_bytes"]["write"] + pmc["frame_hbm_bytes"]["fetch_raw"]
-                nv = pmc.get("sq_counters_bench_scene_per_launch", {}).get("render_kernel", {}).get("SQ_INSTS_VALU")
-                nl = pmc.get("sq_counters_bench_scene_per_launch", {}).get("build_tile_lists_kernel", {}).get("SQ_INSTS_VALU", 0.0)
-                if nv:
-                    rate = nv / (kernel_ms * 1e-3)
-                    frame_rate = (nv + nl) / (ms_per_step * 1e-3)   # all VALU work of a frame over the frame time
-                    valu = {"wave_instructions_per_launch": nv, "achieved_per_s": rate, "peak_per_s": VALU_PEAK_WAVE_INSTR,
-                            "frac": rate / VALU_PEAK_WAVE_INSTR, "source": "profiles/r01d_pmc_traffic.json (SQ_INSTS_VALU)",
-                            "frame": {"wave_instructions": nv + nl, "achieved_per_s": frame_rate, "frac": frame_rate / VALU_PEAK_WAVE_INSTR}}
-        except (OSError, KeyError, ValueError):
+        # ---- VALU (what actually bounds the path).  ALGORITHMIC lane-ops: per (ray, candidate of its block)
+        # one cull / precompute = 14 lane-ops, per surviving (emitter i, sample k, absorber j) of a ray 16 lane-ops
+        # (1 fma + A&S erf with 1 rcp + 1 fma); both counted by the statistics pass above, nothing skipped is credited.
+        # 64 lane-ops = one wave-instruction equivalent.
+        culls = 64 * st["list_entries"]
+        terms = 5 * st["lane_pairs"]
+        alg_wave_instr = (14 * culls + 16 * terms) / 64.0
+        valu = {"algorithmic": {"ray_candidate_culls": culls, "surviving_ikj_terms": terms,
+                                "lane_ops": 14 * culls + 16 * terms, "wave_instruction_equivalents": alg_wave_instr,
+                                "achieved_per_s": alg_wave_instr / (kernel_ms * 1e-3),
+                                "frac": alg_wave_instr / (kernel_ms * 1e-3) / VALU_PEAK_WAVE_INSTR,
+                                "frac_serial_launch": alg_wave_instr / (kt["render_serial_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTR},
+                "peak_per_s": VALU_PEAK_WAVE_INSTR,
+                "peak_note": "spec: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
+        try:
+            valu["measured_fma_issue"] = json.load(open(VALU_MEASURED_FILE))
+        except (OSError, ValueError):
             pass
+        # ---- constants from separate PMC passes (rocprofv3 --pmc cannot run inside this process): HBM traffic and
+        # EXECUTED instruction counts per launch.  Used only when they were taken with these very kernel sources.
+        traffic, traffic_frame = None, None
+        pmc_path, pmc = latest_pmc_summary()
+        sha = kernel_source_sha()
+        if pmc is not None and world == 1 and args.grid == 64 and w == 2048 and not args.plane_arrays:
+            if pmc.get("kernel_source_sha") == sha:
+                try:
+                    traffic = pmc["render_kernel_traffic_bytes_per_launch"]["lower"]
+                    traffic_frame = pmc["frame_hbm_bytes"]["write"] + pmc["frame_hbm_bytes"]["fetch_raw"]
+                    sq = pmc.get("sq_counters_bench_scene_per_launch", {})
+                    nv = sq.get("render_kernel", {}).get("SQ_INSTS_VALU")
+                    nl = sq.get("build_tile_lists_kernel", {}).get("SQ_INSTS_VALU", 0.0)
+                    if nv:
+                        rate = nv / (kernel_ms * 1e-3)
+                        valu["executed"] = {"wave_instructions_per_launch": nv, "achieved_per_s": rate,
+                                            "frac": rate / VALU_PEAK_WAVE_INSTR,
+                                            "frac_serial_launch": nv / (kt["render_serial_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTR,
+                                            "algorithmic_share": alg_wave_instr / nv,
+                                            "frame_wave_instructions": nv + nl}
+                    valu["from"] = {"file": pmc_path, "kernel_source_sha": sha, "kind": "constants of separate --pmc passes"}
+                except KeyError:
+                    traffic, traffic_frame = None, None
+            else:
+                valu["from"] = {"file": pmc_path, "dropped": "taken with other kernel sources "
+                                f"({pmc.get('kernel_source_sha')} != {sha}): traffic and executed counts omitted"}
         result = {
             "metric": "Mrays/sec (whole node), 2048^2 image, 64x64 Gaussian grid", "value": rays / elapsed / 1e6,
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            # ms/frame of the metric = what ONE caller of the vrt:: API waits for a frame (strictly serial frames on one
+            # context, measured after the timed region); ms_per_step is the timed loop's wall time per step, which with
+            # two frames in flight is a throughput figure
+            "ms_per_frame": serial_ms if solo else ms_per_step,
             "higher_is_better": True, "scaling": "weak" if (solo and world > 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"-g {args.grid} -w {w} (tiles {args.tiles}, mode-8 packing, cull_eps {args.cull_eps:g}, "
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
@@ -307,6 +393,7 @@ def main():
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": render_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_from": (valu.get("from") if traffic is not None else None),
                          "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": render_bytes,
                          # an event pair with nothing between reads ~4.6 us on this stack: rocprofv3's kernel duration
                          # (profiles/) is the event figure minus that.  `achieved` uses the raw (larger) event figure.
@@ -322,10 +409,10 @@ def main():
                                  "context's kernels (launch_sequence_ms: the same kernels alone)"},
             # the same loop with one context: frame k+1 starts when frame k is done
             "serial": {"frames_in_flight": 1, "ms_per_step": serial_ms, "value": w * h / (serial_ms * 1e-3) / 1e6, "steps": n_serial},
-            "valu": {"issue": valu, "blocks": st["blocks"], "shaded_blocks": st["shaded_blocks"], "dense_blocks": st["dense_blocks"],
+            "valu": {**valu, "blocks": st["blocks"], "shaded_blocks": st["shaded_blocks"], "dense_blocks": st["dense_blocks"],
                      "mean_cell_list": st["tile_entries"] / sb, "mean_block_list": st["list_entries"] / sb,
                      "mean_ray_list": st["lane_entries"] / (sb * 64), "mean_block_longest_ray_list": st["lane_max_entries"] / sb,
-                     "slow_path_blocks": st["overflow_blocks"]},
+                     "dense_overflow_blocks": st["overflow_blocks"]},
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(scene, g, w, h, args.tiles, args.grid, "")

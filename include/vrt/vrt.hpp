@@ -1,8 +1,9 @@
 // vrt.hpp -- C++ host-side mirror of the reference's vrt:: interface for the hot path, implemented
 // on the C ABI of libvrt_hip.so (include/vrt_hip.h).  Same names, argument meaning and return values as
-//   src/vrt/types.h   vec4f_t, gaussian_t, gaussian_vec_t, gaussians_t, tiles_t
+//   src/vrt/types.h   vec4f_t, simd_vec4f_t, gaussian_t, simd_gaussian_t, gaussian_vec_t, gaussians_t, tiles_t
 //   src/vrt/camera.h  camera_t, camera_create_info_t
-//   src/vrt/rt.h      transmittance, radiance, render_image (2 overloads), simd_render_image (2 overloads),
+//   src/vrt/rt.h      transmittance, simd_transmittance, broadcast_transmittance, radiance, simd_radiance,
+//                     broadcast_radiance, render_image (2 overloads), simd_render_image (2 overloads),
 //                     tile_gaussians, transmittance_step, density
 //   src/vrt/gaussians-from-file.h  read_from_obj
 // so that the reference's callers (volumetric-ray-tracer/main.cpp:257-296, tests/transmittance.cpp,
@@ -20,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -63,6 +65,45 @@ struct gaussian_t {
 };
 static_assert(sizeof(gaussian_t) == 40, "gaussian_t must match the reference's AoS layout");
 
+// ---- types.h:115-193, 289-306: the W-wide twins.  The reference's W is the host's SIMD width (16 on AVX-512, 8 on
+//      AVX2); here a lane is a ray of a wave64, so W = 64 and simd::Vec<simd::Float> is a plain array of 64 floats.
+//      They exist so that callers of broadcast_transmittance / broadcast_radiance (rt.h:102-103, 205-206) compile:
+//      the arithmetic on them happens on the GPU, one lane per ray.  (simd_gaussian_t::pdf has no host evaluator: the
+//      density is evaluated inside the kernels, types.h:299-302 <-> emission_term in csrc/vrt_kernels.hip.) ---------
+constexpr u64 SIMD_FLOATS = 64;
+namespace simd {
+struct Float {};
+template <typename T> struct Vec;
+template <> struct Vec<Float> {
+    std::array<f32, SIMD_FLOATS> v;
+    f32 &operator[](size_t i) { return v[i]; }
+    const f32 &operator[](size_t i) const { return v[i]; }
+};
+template <typename T> inline Vec<T> set1(f32 x) { Vec<T> r; r.v.fill(x); return r; }
+inline void store(f32 *p, const Vec<Float> &a) { std::memcpy(p, a.v.data(), sizeof a.v); }
+inline Vec<Float> load(const f32 *p) { Vec<Float> r; std::memcpy(r.v.data(), p, sizeof r.v); return r; }
+} // namespace simd
+
+struct simd_vec4f_t {
+    simd::Vec<simd::Float> x, y, z, w = simd::set1<simd::Float>(0.f);
+    static simd_vec4f_t from_vec4f_t(const vec4f_t &o) // types.h:183-192
+    {
+        return { simd::set1<simd::Float>(o.x), simd::set1<simd::Float>(o.y), simd::set1<simd::Float>(o.z), simd::set1<simd::Float>(o.w) };
+    }
+    vec4f_t lane(size_t i) const { return { x[i], y[i], z[i], w[i] }; }
+    void set_lane(size_t i, const vec4f_t &o) { x[i] = o.x; y[i] = o.y; z[i] = o.z; w[i] = o.w; }
+};
+
+struct simd_gaussian_t {
+    simd_vec4f_t albedo, mu;
+    simd::Vec<simd::Float> sigma, magnitude;
+    static simd_gaussian_t from_gaussian_t(const gaussian_t &g) // types.cpp:113-121
+    {
+        return { simd_vec4f_t::from_vec4f_t(g.albedo), simd_vec4f_t::from_vec4f_t(g.mu), simd::set1<simd::Float>(g.sigma),
+                 simd::set1<simd::Float>(g.magnitude) };
+    }
+};
+
 // ---- types.h:232-264: SoA mirror (padded to (n/W+1)*W with sigma 1, magnitude 0; W = 16) --------------
 struct gaussian_vec_t {
     struct { std::vector<f32> r, g, b; } albedo;
@@ -94,12 +135,17 @@ struct gaussians_t {
     gaussian_vec_t *soa_gaussians = nullptr;
 };
 
-// ---- types.h:272-287.  The per-tile sets live on the device; `counts` mirrors gaussians[t].size() ---------
+// ---- types.h:272-287.  The reference's tiles_t OWNS a copy of every tile's Gaussians; here the per-tile sets live on
+//      the device as index lists, and the object keeps what is needed to rebuild them (the scene it was made from, the
+//      tile size and the view matrix): a tiles_t stays valid whatever the process renders in between -- an untiled
+//      render, another scene, another tiling -- the tiled overloads re-bin when the device no longer holds THIS set. ---
 struct tiles_t {
     f32 tw, th;
     u64 w, h;
-    std::vector<u32> counts; // per tile, row-major
-    u64 generation;          // device-side tile set this object names (see tile_gaussians)
+    std::vector<u32> counts; // per tile, row-major: gaussians[t].gaussians.size() of the reference
+    std::shared_ptr<const std::vector<gaussian_t>> scene;
+    std::array<f32, 16> view;
+    mutable u64 generation;  // device state (detail::device_t::generation) that holds this tile set
 };
 
 // ---- camera.h:7-44, camera.cpp:7-79 (own 3-vector maths; view_matrix is column-major like glm::mat4) ------
@@ -126,57 +172,54 @@ struct camera_t {
     explicit camera_t(const camera_create_info_t &ci)
         : camera_t(ci.position, ci.up, ci.front, ci.yaw, ci.pitch, ci.width, ci.height, ci.focal_length) {}
 
-    // camera.cpp:7-23
+    // camera.cpp:7-23.  The arithmetic is the library's (vrt_hip_camera_*, csrc/vrt_host_camera.cpp): glm's lookAt ->
+    // translate -> inverse -> mat4*vec4 in glm's order of operations, compiled once without contraction or fast-math,
+    // so the view matrix and the plane points do not depend on the flags THIS header is compiled with -- a last-bit
+    // difference in a ray shows up as up to 5e-4 of radiance for small sigma.
     void turn(const f32 yaw, const f32 pitch, const bool constrain = true)
     {
-        f32 p = pitch;
-        if (constrain) { p = p > 89.f ? 89.f : p; p = p < -89.f ? -89.f : p; }
-        const f32 ry = radians(yaw), rp = radians(p);
-        front = normalize3({ std::cos(ry) * std::cos(rp), std::sin(rp), std::sin(ry) * std::cos(rp) });
-        right = normalize3(cross(front, world_up));
-        up = normalize3(cross(right, front));
-        update();
+        vrt_hip_camera c = to_c();
+        vrt_hip_camera_turn(&c, yaw, pitch, constrain ? 1 : 0);
+        from_c(c);
+        planes(c);
     }
-    // camera.cpp:50-71: view = translate(lookAt(pos, pos+front, up), focal*front); plane = inverse(view)*(x,y,0,1),
-    // evaluated through its closed form plane = pos + x*right + y*up - focal*front
+    // camera.cpp:50-71: view = translate(lookAt(pos, pos + front, up), focal * front); plane = inverse(view) * (x, y, 0, 1)
     void update()
     {
-        std::array<f32, 16> &m = view_matrix;
-        m.fill(0.f);
-        m[0] = right[0]; m[4] = right[1]; m[8] = right[2];
-        m[1] = up[0]; m[5] = up[1]; m[9] = up[2];
-        m[2] = -front[0]; m[6] = -front[1]; m[10] = -front[2];
-        m[12] = -dot3(right, position); m[13] = -dot3(up, position); m[14] = dot3(front, position); m[15] = 1.f;
-        const f32 t[3] = { focal_length * front[0], focal_length * front[1], focal_length * front[2] };
-        for (int r = 0; r < 4; ++r) m[12 + r] = m[r] * t[0] + m[4 + r] * t[1] + m[8 + r] * t[2] + m[12 + r];
-        projection_plane.xs.resize(w * h); projection_plane.ys.resize(w * h); projection_plane.zs.resize(w * h);
-        for (u64 i = 0; i < h; ++i)
-            for (u64 j = 0; j < w; ++j) {
-                const f32 x = -1.f + j / (w / 2.f), y = -1.f + i / (h / 2.f);
-                projection_plane.xs[i * w + j] = position[0] + x * right[0] + y * up[0] - focal_length * front[0];
-                projection_plane.ys[i * w + j] = position[1] + x * right[1] + y * up[1] - focal_length * front[1];
-                projection_plane.zs[i * w + j] = position[2] + x * right[2] + y * up[2] - focal_length * front[2];
-            }
+        vrt_hip_camera c = to_c();
+        vrt_hip_camera_refresh(&c); // front / right / up as they are (camera_t::update does not re-derive them)
+        from_c(c);
+        planes(c);
     }
-    // main.cpp:330-334: position = rotate(I, radians(deg), +Y) * position
+    // main.cpp:252, 330: position = rotate(I, radians(deg), +Y) * position (follow with turn(angle - deg, 0))
     void orbit(const f32 deg)
     {
-        const f32 a = radians(deg), c = std::cos(a), s = std::sin(a);
-        const f32 x = position[0], z = position[2];
-        position[0] = c * x + s * z;
-        position[2] = -s * x + c * z;
+        vrt_hip_camera c = to_c();
+        vrt_hip_camera_orbit(&c, deg);
+        for (int i = 0; i < 3; ++i) position[i] = c.position[i];
     }
 
-    static f32 radians(f32 d) { return d * 0.01745329251994329576923690768489f; }
-    static f32 dot3(const std::array<f32, 3> &a, const std::array<f32, 3> &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-    static std::array<f32, 3> cross(const std::array<f32, 3> &a, const std::array<f32, 3> &b)
+private:
+    vrt_hip_camera to_c() const
     {
-        return { a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1] };
+        vrt_hip_camera c;
+        std::memset(&c, 0, sizeof c);
+        for (int i = 0; i < 3; ++i) {
+            c.position[i] = position[i]; c.front[i] = front[i]; c.up[i] = up[i]; c.world_up[i] = world_up[i]; c.right[i] = right[i];
+        }
+        for (int i = 0; i < 16; ++i) c.view[i] = view_matrix[i];
+        c.focal_length = focal_length; c.w = w; c.h = h;
+        return c;
     }
-    static std::array<f32, 3> normalize3(const std::array<f32, 3> &a)
+    void from_c(const vrt_hip_camera &c)
     {
-        const f32 inv = 1.f / std::sqrt(dot3(a, a));
-        return { a[0] * inv, a[1] * inv, a[2] * inv };
+        for (int i = 0; i < 3; ++i) { front[i] = c.front[i]; up[i] = c.up[i]; right[i] = c.right[i]; }
+        for (int i = 0; i < 16; ++i) view_matrix[i] = c.view[i];
+    }
+    void planes(const vrt_hip_camera &c)
+    {
+        projection_plane.xs.resize(w * h); projection_plane.ys.resize(w * h); projection_plane.zs.resize(w * h);
+        vrt_hip_camera_plane(&c, projection_plane.xs.data(), projection_plane.ys.data(), projection_plane.zs.data());
     }
 };
 
@@ -187,7 +230,7 @@ struct device_t {
     const void *scene_key = nullptr; // identity of the last uploaded Gaussian vector
     size_t scene_n = 0;
     u64 scene_hash = 0;
-    u64 tiles_generation = 0;
+    u64 generation = 0;   // bumped whenever the device's scene or tile sets change: names what the device holds
     const f32 *plane_key = nullptr;
     u64 plane_w = 0, plane_h = 0;
     f32 cull_eps = 1e-9f;
@@ -220,11 +263,17 @@ struct device_t {
         if (scene_n == g.size() && scene_hash == h && scene_key) return;
         check(vrt_hip_set_gaussians_aos(ctx, g.size(), g.data()), "vrt_hip_set_gaussians_aos");
         scene_key = g.data(); scene_n = g.size(); scene_hash = h;
+        ++generation; // tile sets of the old scene are gone
     }
     void upload_plane(const camera_t &cam)
     {
         check(vrt_hip_set_plane(ctx, (u32)cam.w, (u32)cam.h, cam.projection_plane.xs.data(), cam.projection_plane.ys.data(),
                                 cam.projection_plane.zs.data()), "vrt_hip_set_plane");
+    }
+    void untiled()
+    {
+        check(vrt_hip_clear_tiles(ctx), "vrt_hip_clear_tiles");
+        ++generation;
     }
     void options(exp_kind e, erf_kind r) { check(vrt_hip_set_options(ctx, (int)e, (int)r, cull_eps), "vrt_hip_set_options"); }
 };
@@ -237,7 +286,7 @@ inline tiles_t tile_gaussians(const f32 tw, const f32 th, const std::vector<gaus
     auto &d = detail::device_t::get();
     d.upload_scene(gaussians);
     d.check(vrt_hip_tile_gaussians(d.ctx, tw, th, view.data()), "vrt_hip_tile_gaussians");
-    tiles_t t{ tw, th, 0, 0, {}, ++d.tiles_generation };
+    tiles_t t{ tw, th, 0, 0, {}, std::make_shared<const std::vector<gaussian_t>>(gaussians), view, ++d.generation };
     d.check(vrt_hip_get_tile_counts(d.ctx, nullptr, 0, &t.w, &t.h), "vrt_hip_get_tile_counts");
     t.counts.resize(t.w * t.h);
     d.check(vrt_hip_get_tile_counts(d.ctx, t.counts.data(), t.counts.size(), nullptr, nullptr), "vrt_hip_get_tile_counts");
@@ -257,6 +306,16 @@ inline bool render(u32 width, u32 height, u32 *image, const camera_t &cam, const
     d.check(vrt_hip_render(d.ctx, o, pack, image, nullptr), "vrt_hip_render");
     return !running; // the reference returns true when the viewer asked to stop (rt.h:244, 308, 334, 402)
 }
+// make the device hold `tiles` (its scene and its tile sets) before a tiled render
+inline void bind_tiles(const tiles_t &tiles)
+{
+    auto &d = device_t::get();
+    if (tiles.generation == d.generation) return;
+    if (!tiles.scene) throw hip_error("tiles_t was not made by vrt::tile_gaussians");
+    d.upload_scene(*tiles.scene);
+    d.check(vrt_hip_tile_gaussians_device(d.ctx, tiles.tw, tiles.th, tiles.view.data(), nullptr), "vrt_hip_tile_gaussians");
+    tiles.generation = ++d.generation;
+}
 } // namespace detail
 
 // ---- rt.h:227-247: scalar render, untiled: truncating pack, opaque alpha ------------------------------------------
@@ -266,7 +325,7 @@ bool render_image(const u32 width, const u32 height, u32 *image, const camera_t 
 {
     auto &d = detail::device_t::get();
     d.upload_scene(gaussians.gaussians);
-    d.check(vrt_hip_clear_tiles(d.ctx), "vrt_hip_clear_tiles");
+    d.untiled();
     return detail::render(width, height, image, cam, origin, VRT_PACK_TRUNC | VRT_ALPHA_OPAQUE, Exp, Erf, running);
 }
 // ---- rt.h:251-310: scalar render, tiled (tc = thread count: the GPU grid replaces the pool) -----------------------
@@ -274,8 +333,7 @@ template <exp_kind Exp = exp_kind::libm, erf_kind Erf = erf_kind::libm>
 bool render_image(const u32 width, const u32 height, u32 *image, const camera_t &cam, const vec4f_t &origin,
                   const tiles_t &tiles, const bool &running, const u64 /*tc*/)
 {
-    auto &d = detail::device_t::get();
-    if (tiles.generation != d.tiles_generation) throw hip_error("render_image: stale tiles_t (call tile_gaussians again)");
+    detail::bind_tiles(tiles);
     return detail::render(width, height, image, cam, origin, VRT_PACK_TRUNC | VRT_ALPHA_OPAQUE, Exp, Erf, running);
 }
 // ---- rt.h:315-337: SIMD-over-pixels render, untiled: rounding pack, opaque alpha ----------------------------------
@@ -285,7 +343,7 @@ bool simd_render_image(const u32 width, const u32 height, u32 *image, const came
 {
     auto &d = detail::device_t::get();
     d.upload_scene(gaussians.gaussians);
-    d.check(vrt_hip_clear_tiles(d.ctx), "vrt_hip_clear_tiles");
+    d.untiled();
     return detail::render(width, height, image, cam, origin, VRT_PACK_ROUND | VRT_ALPHA_OPAQUE, Exp, Erf, running);
 }
 // ---- rt.h:344-404: SIMD-over-pixels render, tiled (the CLI default, mode 8): rounding pack, computed alpha --------
@@ -293,8 +351,7 @@ template <exp_kind Exp = exp_kind::vcl, erf_kind Erf = erf_kind::abramowitz_steg
 bool simd_render_image(const u32 width, const u32 height, u32 *image, const camera_t &cam, const vec4f_t origin,
                        const tiles_t &tiles, const bool &running, const u64 /*tc*/)
 {
-    auto &d = detail::device_t::get();
-    if (tiles.generation != d.tiles_generation) throw hip_error("simd_render_image: stale tiles_t (call tile_gaussians again)");
+    detail::bind_tiles(tiles);
     return detail::render(width, height, image, cam, origin, VRT_PACK_ROUND | VRT_ALPHA_COMPUTED, Exp, Erf, running);
 }
 
@@ -312,6 +369,23 @@ f32 transmittance(const vec4f_t o, const vec4f_t n, const f32 s, const gaussians
 }
 template <exp_kind Exp = exp_kind::vcl, erf_kind Erf = erf_kind::abramowitz_stegun>
 f32 simd_transmittance(const vec4f_t o, const vec4f_t n, const f32 s, const gaussians_t &g) { return transmittance<Exp, Erf>(o, n, s, g); }
+// ---- rt.h:102-127: SIMD_FLOATS rays at once, each with its own origin, direction and sample point -------------------
+template <exp_kind Exp = exp_kind::vcl, erf_kind Erf = erf_kind::abramowitz_stegun>
+simd::Vec<simd::Float> broadcast_transmittance(const simd_vec4f_t &o, const simd_vec4f_t &n, const simd::Vec<simd::Float> &s,
+                                               const gaussians_t &gaussians)
+{
+    auto &d = detail::device_t::get();
+    d.upload_scene(gaussians.gaussians);
+    d.options(Exp, Erf);
+    f32 oo[3 * SIMD_FLOATS], nn[3 * SIMD_FLOATS];
+    for (u64 l = 0; l < SIMD_FLOATS; ++l) {
+        oo[3 * l] = o.x[l]; oo[3 * l + 1] = o.y[l]; oo[3 * l + 2] = o.z[l];
+        nn[3 * l] = n.x[l]; nn[3 * l + 1] = n.y[l]; nn[3 * l + 2] = n.z[l];
+    }
+    simd::Vec<simd::Float> T;
+    d.check(vrt_hip_transmittance_rays(d.ctx, SIMD_FLOATS, oo, nn, s.v.data(), T.v.data()), "vrt_hip_transmittance_rays");
+    return T;
+}
 
 // ---- rt.h:146-164 / 166-199 / 205-223: L_hat incl. w = sum albedo.w * inner ------------------------------------------
 template <exp_kind Exp = exp_kind::libm, erf_kind Erf = erf_kind::libm>
@@ -327,6 +401,23 @@ vec4f_t radiance(const vec4f_t o, const vec4f_t n, const gaussians_t &gaussians)
 }
 template <exp_kind Exp = exp_kind::vcl, erf_kind Erf = erf_kind::abramowitz_stegun>
 vec4f_t simd_radiance(const vec4f_t o, const vec4f_t n, const gaussians_t &g) { return radiance<Exp, Erf>(o, n, g); }
+// ---- rt.h:205-223: SIMD_FLOATS rays at once (lane = ray); the kernel the tiled renderer runs per pixel vector --------
+template <exp_kind Exp = exp_kind::vcl, erf_kind Erf = erf_kind::abramowitz_stegun>
+simd_vec4f_t broadcast_radiance(const simd_vec4f_t o, const simd_vec4f_t n, const gaussians_t &gaussians)
+{
+    auto &d = detail::device_t::get();
+    d.upload_scene(gaussians.gaussians);
+    d.options(Exp, Erf);
+    f32 oo[3 * SIMD_FLOATS], nn[3 * SIMD_FLOATS], out[4 * SIMD_FLOATS];
+    for (u64 l = 0; l < SIMD_FLOATS; ++l) {
+        oo[3 * l] = o.x[l]; oo[3 * l + 1] = o.y[l]; oo[3 * l + 2] = o.z[l];
+        nn[3 * l] = n.x[l]; nn[3 * l + 1] = n.y[l]; nn[3 * l + 2] = n.z[l];
+    }
+    d.check(vrt_hip_radiance(d.ctx, SIMD_FLOATS, oo, nn, out), "vrt_hip_radiance");
+    simd_vec4f_t L;
+    for (u64 l = 0; l < SIMD_FLOATS; ++l) L.set_lane(l, { out[4 * l], out[4 * l + 1], out[4 * l + 2], out[4 * l + 3] });
+    return L;
+}
 
 // ---- rt.cpp:8-27 -----------------------------------------------------------------------------------------------------
 inline f32 transmittance_step(const vec4f_t o, const vec4f_t n, const f32 s, const f32 delta, const std::vector<gaussian_t> gaussians)

@@ -108,6 +108,32 @@ int vrt_hip_set_camera(vrt_hip_ctx *ctx, uint32_t w, uint32_t h, const float pos
  * points -- which the reference's |oc|^2 - mubar^2 can amplify to 1e-4 for small sigma.) */
 int vrt_hip_set_camera_view(vrt_hip_ctx *ctx, uint32_t width, uint32_t height, const float view[16]);
 
+/* -------- host camera: replaces camera_t (camera.h:20-44, camera.cpp:7-71) -------------------------------- */
+/* Pure host code (no GPU needed, no context): the reference's yaw/pitch camera evaluated in glm's order of operations
+ * (lookAtRH -> translate -> inverse -> mat4*vec4, unfused), so that view matrices and projection-plane points are the
+ * reference's to the last bit whatever floating-point flags the CALLER is compiled with (csrc/vrt_host_camera.cpp).
+ * Field meaning as in camera_t; `view` is camera_t::view_matrix, column-major (glm::mat4 layout). */
+typedef struct {
+    float position[3], front[3], up[3], world_up[3], right[3];
+    float view[16];
+    float focal_length;
+    uint64_t w, h;
+} vrt_hip_camera;
+/* camera_t::camera_t (camera.cpp:25-36): stores the arguments, then turn(yaw, pitch). */
+void vrt_hip_camera_init(vrt_hip_camera *cam, const float position[3], const float up[3], const float front[3],
+                         float yaw, float pitch, uint64_t w, uint64_t h, float focal_length);
+/* camera_t::turn (camera.cpp:7-23) + the view-matrix half of update() (camera.cpp:52); position is read as it is. */
+void vrt_hip_camera_turn(vrt_hip_camera *cam, float yaw, float pitch, int constrain);
+/* The view-matrix half of camera_t::update() alone (camera.cpp:52), from position / front / up / focal_length as stored. */
+void vrt_hip_camera_refresh(vrt_hip_camera *cam);
+/* The projection-plane half of camera_t::update() (camera.cpp:54-70): three w*h arrays, caller-allocated. */
+void vrt_hip_camera_plane(const vrt_hip_camera *cam, float *xs, float *ys, float *zs);
+/* The orbit step of the frame loop (main.cpp:252, 330): position = rotate(I, radians(deg), +Y) * (position, 1).
+ * The caller follows it with `angle -= deg; turn(angle, 0)` like main.cpp:254-255, 332-333. */
+void vrt_hip_camera_orbit(vrt_hip_camera *cam, float deg);
+/* glm::inverse(mat4) in glm's order of operations (what camera.cpp:62 applies to view_matrix). */
+void vrt_hip_mat4_inverse(const float m[16], float out[16]);
+
 /* -------- options ---------------------------------------------------------------------- */
 /* exp_kind / erf_kind: the reference's template arguments.  cull_eps: Gaussians whose
  * sigma*magnitude*exp(-d^2/(2 sigma^2)) is below cull_eps for every ray of an 8x8 pixel
@@ -154,6 +180,10 @@ int vrt_hip_assemble_shards_strided_device(vrt_hip_ctx *ctx, const uint32_t *d_g
 /* T_out[k] = transmittance<Exp,Erf>(o, n, s[k], all Gaussians of the scene), rt.h:32-54. */
 int vrt_hip_transmittance(vrt_hip_ctx *ctx, const float o[3], const float n[3], const float *s, size_t ns,
                           float *T_out);
+/* T_out[r] = broadcast_transmittance (rt.h:102-127): ray r has its own origin origins[3*r..], unit direction
+ * dirs[3*r..] and sample point s[r]; all Gaussians of the scene. */
+int vrt_hip_transmittance_rays(vrt_hip_ctx *ctx, size_t nrays, const float *origins, const float *dirs, const float *s,
+                               float *T_out);
 /* out[4*r..] = radiance / broadcast_radiance (rt.h:146-164, 205-223) for ray r with origin
  * origins[3*r..], unit direction dirs[3*r..], over all Gaussians of the scene (no tiling). */
 int vrt_hip_radiance(vrt_hip_ctx *ctx, size_t nrays, const float *origins, const float *dirs, float *out);
@@ -181,15 +211,15 @@ typedef struct {
     uint64_t blocks;         /* 8x8 pixel blocks (one wavefront each)                                */
     uint64_t list_entries;   /* sum over blocks of candidates kept by the block cull                 */
     uint64_t tile_entries;   /* sum over blocks of the (tile-culled) tile list length they scanned    */
-    uint64_t overflow_blocks;/* blocks whose candidates overflowed LDS (streamed the tile list)       */
+    uint64_t overflow_blocks;/* dense-kernel blocks with more than 1024 survivors (streamed from scratch)      */
     uint64_t lane_entries;   /* sum over rays of the per-ray list length (fast path)                  */
     uint64_t lane_max_entries;/* sum over blocks of the longest per-ray list (the loop trip count)    */
     uint64_t shaded_blocks;  /* blocks that reached the shading loops (the rest were only cleared)    */
     uint64_t dense_blocks;   /* of those, blocks shaded by the 16-waves-per-block kernel              */
     double dense_busy_frac;  /* mean share of that kernel's duration its workgroups had blocks to work on */
     uint64_t table_blocks;   /* of the dense blocks, those shaded through the interpolation table (vrt_hip_set_table_step) */
-    uint64_t slow_path_total;/* running count (since create) of blocks the one-wave kernel had to shade through its
-                                one-wave-streams-the-whole-list fallback because no dense kernel was launched behind it */
+    uint64_t lane_pairs;     /* sum over rays of (per-ray list length)^2: the (emitter, absorber) pairs the one-wave
+                                kernel has to evaluate, 5 erf terms each -- the ALGORITHMIC work of its pair loops    */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

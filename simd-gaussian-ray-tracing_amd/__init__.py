@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("list_entries", C.c_uint64), ("tile_entries", C.c_uint64), ("overflow_blocks", C.c_uint64),
                 ("lane_entries", C.c_uint64), ("lane_max_entries", C.c_uint64), ("shaded_blocks", C.c_uint64), ("dense_blocks", C.c_uint64),
                 ("dense_busy_frac", C.c_double), ("table_blocks", C.c_uint64),
-                ("slow_path_total", C.c_uint64)]
+                ("lane_pairs", C.c_uint64)]
 
 
 def build(verbose=False):
@@ -76,11 +76,18 @@ SYMBOLS = {
     "vrt_hip_assemble_shards_device": (C.c_int, [_vp, _vp, _vp, _vp]),
     "vrt_hip_assemble_shards_strided_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "vrt_hip_transmittance": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, _f32p]),
+    "vrt_hip_transmittance_rays": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p, _f32p]),
     "vrt_hip_radiance": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p]),
     "vrt_hip_transmittance_step": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, C.c_float, _f32p]),
     "vrt_hip_density": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p]),
     "vrt_hip_eval_erf": (C.c_int, [_vp, C.c_int, _f32p, C.c_size_t, _f32p]),
     "vrt_hip_eval_exp": (C.c_int, [_vp, C.c_int, _f32p, C.c_size_t, _f32p]),
+    "vrt_hip_camera_init": (None, [_vp, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_float]),
+    "vrt_hip_camera_turn": (None, [_vp, C.c_float, C.c_float, C.c_int]),
+    "vrt_hip_camera_refresh": (None, [_vp]),
+    "vrt_hip_camera_plane": (None, [_vp, _f32p, _f32p, _f32p]),
+    "vrt_hip_camera_orbit": (None, [_vp, C.c_float]),
+    "vrt_hip_mat4_inverse": (None, [_f32p, _f32p]),
     "vrt_hip_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "vrt_hip_enable_stats": (C.c_int, [_vp, C.c_int]),
     "vrt_hip_enable_kernel_timing": (C.c_int, [_vp, C.c_int]),
@@ -274,6 +281,17 @@ class Renderer:
         out = np.zeros_like(s)
         self._chk(self._L.vrt_hip_transmittance(self._h, _fp(_f3(o)), _fp(_f3(n)), _fp(s), s.size, _fp(out)),
                   "transmittance")
+        return out
+
+    def transmittance_rays(self, origins, dirs, s):
+        """broadcast_transmittance (rt.h:102-127): one sample point per ray."""
+        origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        s = np.ascontiguousarray(s, np.float32).ravel()
+        assert len(origins) == len(dirs) == s.size
+        out = np.zeros_like(s)
+        self._chk(self._L.vrt_hip_transmittance_rays(self._h, s.size, _fp(origins), _fp(dirs), _fp(s), _fp(out)),
+                  "transmittance_rays")
         return out
 
     def transmittance_step(self, o, n, s, delta):

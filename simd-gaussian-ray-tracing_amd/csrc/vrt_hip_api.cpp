@@ -50,6 +50,9 @@ enum TileMode { TILES_NONE = 0, TILES_HOST = 1, TILES_DEVICE = 2 };
 struct vrt_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // the caller's stream the last *_device call enqueued on (may differ from `stream`): state-changing calls wait for
+    // it before they touch buffers its kernels may still be reading (quiesce)
+    hipStream_t last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
 
@@ -85,10 +88,7 @@ struct vrt_hip_ctx {
     // dense-launch feedback (CellGrid::feedback): host-mapped, read frames later
     volatile uint32_t *h_fb = nullptr;
     uint32_t *d_fb = nullptr;
-    bool fb_valid = false;        // at least one frame of the current scene/options has reported
-    bool dense_launched_last = true;
-    uint32_t fb1_seen = 0;
-    // dense-launch prediction: frame_seq counts render launches; a report in h_fb[3] (the sequence number of the frame
+    // dense-launch sizing: frame_seq counts render launches; a report in h_fb[3] (the sequence number of the frame
     // that wrote it) newer than reset_seq comes from the current scene / camera / options
     uint32_t frame_seq = 0, reset_seq = 0;
     int num_cus = 256;
@@ -154,6 +154,21 @@ int fail(vrt_hip_ctx *c, int code, const std::string &msg)
             return fail((c), VRT_HIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+// Frames enqueued through the *_device entry points run on the CALLER's stream and read the context's tables, lists
+// and plane arrays.  Every call that rewrites one of those waits here first -- for the context's own stream and for the
+// stream of the last enqueued frame -- so a caller may change state right after enqueueing frames without a
+// synchronisation of its own (include/vrt_hip.h, "Streams").  An error from the caller's stream (it may have been
+// destroyed, which completes its work) is not this call's error.
+int quiesce(vrt_hip_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->last_stream && c->last_stream != c->stream) {
+        if (hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
+    }
+    c->last_stream = nullptr;
+    return VRT_HIP_OK;
+}
+
 float exp_floor_x(int exp_kind)
 {
     // Exp(-x) is exactly 0 past this point for the chosen Exp, so such Gaussians contribute nothing:
@@ -170,6 +185,7 @@ float exp_floor_x(int exp_kind)
 int rebuild_tables(vrt_hip_ctx *c)
 {
     if (!c->tables_dirty) return VRT_HIP_OK;
+    { int rc = quiesce(c); if (rc) return rc; } // frames in flight read the tables this rewrites
     HIPCHK(c, c->mu_sig.reserve(c->n)); HIPCHK(c, c->gA.reserve(c->n)); HIPCHK(c, c->gB.reserve(c->n));
     HIPCHK(c, c->gC.reserve(c->n)); HIPCHK(c, c->gD.reserve(c->n)); HIPCHK(c, c->iota.reserve(c->n));
     launch_build_static(c->n, c->soa[0].p, c->soa[1].p, c->soa[2].p, c->soa[3].p, c->soa[4].p, c->soa[5].p,
@@ -242,6 +258,7 @@ RayGen ray_gen(const vrt_hip_ctx *c, const float origin[3])
 // (Re)builds the tile-centre arrays when the tile grid changes (the reference's float loops, rt.cpp:47-49).
 int prepare_tile_grid(vrt_hip_ctx *c, float tw, float th)
 {
+    { int rc = quiesce(c); if (rc) return rc; } // xc / yc / w_start are read by list kernels in flight
     std::vector<float> xc, yc;
     for (float x = -1.f + tw / 2; x < 1.f; x += tw) { xc.push_back(x); if (xc.size() > 4096) break; }
     for (float y = -1.f + th / 2; y < 1.f; y += th) { yc.push_back(y); if (yc.size() > 4096) break; }
@@ -325,7 +342,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.table_hx = c->table_hx; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
     g.feedback = c->d_fb;
-    g.no_dense = 0;
+    g.dense_is_sorted = 1;
     return g;
 }
 
@@ -374,6 +391,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     if (c->tile_mode == TILES_DEVICE && c->grid_n != c->n) { // the scene was replaced after tile_gaussians()
         HIPCHK(c, hipStreamSynchronize(st));
         if ((rc = prepare_tile_grid(c, c->tw, c->th))) return rc;
+        c->last_stream = st;
         a = bin_args(c);
         a.refine = refine ? 1 : 0; a.R = ray_gen(c, origin);
         a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
@@ -489,6 +507,12 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     const TileLists geo = tile_geometry(c);
     if (geo.tile_w == 0 || geo.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
     const bool use_shard = c->world > 1 || shard_compact;
+    if (c->last_stream && c->last_stream != st && c->last_stream != c->stream) {
+        // another stream than the last frame's: the list kernels of this frame rewrite lists and queue counters that
+        // the previous frame's kernels may still be reading
+        if (hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
+    }
+    c->last_stream = st;
     hipEvent_t *tev = nullptr;
     const bool timed_frame = c->timing_on && (c->timing_frame++ % c->timing_period) == 0;
     if (timed_frame) {
@@ -513,7 +537,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
     const TileLists t = work_lists(c);
     if (o.stats) {
-        HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 12 * sizeof(unsigned long long), st));
+        HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 16 * sizeof(unsigned long long), st));
         HIPCHK(c, hipMemsetAsync(c->d_stats.p + 8, 0xFF, sizeof(unsigned long long), st)); // running minimum
     }
     c->timeline_items = 0;
@@ -531,20 +555,16 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
         HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1) + 3, 0, 4 * sizeof(uint32_t), st));
     c->lists_fresh = false;
-    // Is the dense launch worth its ~12 us?  Frames report (asynchronously, see CellGrid::feedback) how many dense
-    // cells / slow-path blocks they had; a few frames after the last change of scene or options the report of
-    // earlier frames predicts this one.  A wrong "no" costs speed only: the one-wave kernel then shades all itself.
-    bool launch_dense = true;
-    // (the report must come from a frame at least two launches after the last change: the host may be many frames
-    // ahead of the GPU, and a report of an older scene or camera must not switch the dense kernel off)
-    if (c->h_fb && !c->stats_on && (int32_t)(c->h_fb[3] - c->reset_seq) >= 2) {
-        const uint32_t fb0 = c->h_fb[0], fb1 = c->h_fb[1], fb2 = c->h_fb[2];
-        launch_dense = fb0 > 0 || (c->dense_launched_last ? fb2 > 0 : fb1 != c->fb1_seen);
-        c->fb1_seen = fb1;
-    }
-    c->dense_launched_last = launch_dense;
+    // How large a dense launch?  The 16-waves-per-block kernel always runs behind the one-wave kernel (which kernel
+    // shades a block depends on the block alone, so the image never depends on this heuristic); but a full launch --
+    // queue sort + one 1024-thread workgroup per CU -- costs ~12 us even with empty queues.  Frames report
+    // (asynchronously, CellGrid::feedback) what their dense kernel found; once a report has arrived from a frame
+    // launched at least two frames after the last change of scene, rays, camera or options, and it says "nothing",
+    // the launch shrinks to a few workgroups and skips the sort.  A wrong guess costs speed only.
+    bool expect_dense = true;
+    if (c->h_fb && !c->stats_on && (int32_t)(c->h_fb[3] - c->reset_seq) >= 2) expect_dense = c->h_fb[0] > 0 || c->h_fb[2] > 0;
     CellGrid cg = cell_grid(c);
-    cg.no_dense = launch_dense ? 0 : 1;
+    cg.dense_is_sorted = expect_dense ? 1 : 0;
     cg.frame_seq = ++c->frame_seq;
     if (!c->c_rq.p) {
         HIPCHK(c, c->c_rq.reserve(2 * RQ_N * RQ_STRIDE));
@@ -556,10 +576,11 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
     launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
-    // dense queue: one 16-wave workgroup per CU pulls blocks until the queue is empty (exits at once if it is)
-    if (launch_dense) launch_order_dense(cg, st);
-    if (launch_dense) {
-        const uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
+    // dense queue: 16-wave workgroups pull blocks until the queue is empty (they exit at once if it is)
+    if (expect_dense) launch_order_dense(cg, st);
+    {
+        uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
+        if (!expect_dense) dense_grid = std::min(dense_grid, 8u);
         if (c->table_hx > 0.f) {
             // opt-in table mode: the table kernel takes the whole dense queue and hands what it declines to a second
             // queue, which the exact kernel then works off (n_dense reads the always-zero word of the counter set)
@@ -643,7 +664,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        c->d_stats.reserve(12) != hipSuccess) {
+        c->d_stats.reserve(16) != hipSuccess) {
         delete c;
         return fail(nullptr, VRT_HIP_ERR_HIP, "create: stream/event creation failed");
     }
@@ -683,7 +704,7 @@ int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const flo
     for (int i = 0; i < 9; ++i)
         if (n && !src[i] && i != 6) return fail(c, VRT_HIP_ERR_INVALID, "set_gaussians: NULL array");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc = quiesce(c); if (rc) return rc; }
     for (int i = 0; i < 9; ++i) {
         HIPCHK(c, c->soa[i].reserve(n));
         if (n && src[i]) HIPCHK(c, hipMemcpy(c->soa[i].p, src[i], n * sizeof(float), hipMemcpyHostToDevice));
@@ -693,7 +714,13 @@ int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const flo
     c->reset_seq = c->frame_seq;
     c->tables_dirty = true;
     c->lists_dirty = true;
-    if (c->tile_mode != TILES_HOST) c->ref_valid = false;
+    if (c->tile_mode == TILES_HOST) {
+        // caller-made lists index the scene they were validated against (set_tiles checks every index < n): they do
+        // not carry over to another scene -- back to untiled until set_tiles / tile_gaussians is called again
+        c->tile_mode = TILES_NONE; c->tw = c->th = 2.f; c->tiles_w = c->tiles_h = 1;
+        c->shard_dirty = true;
+    }
+    c->ref_valid = false;
     return VRT_HIP_OK;
 }
 
@@ -764,7 +791,7 @@ int vrt_hip_set_tiles(vrt_hip_ctx *c, float tw, float th, uint64_t tiles_w, uint
     for (size_t k = 0; k < total; ++k)
         if (indices[k] >= c->n) return fail(c, VRT_HIP_ERR_INVALID, "set_tiles: index out of range (upload the scene first)");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc = quiesce(c); if (rc) return rc; }
     // exact-size index buffer: build_work_lists sizes its output from ref_indices.cap
     c->ref_indices.release();
     HIPCHK(c, c->ref_start.reserve(nt)); HIPCHK(c, c->ref_count.reserve(nt)); HIPCHK(c, c->ref_indices.reserve(total));
@@ -786,8 +813,7 @@ int vrt_hip_tile_gaussians_device(vrt_hip_ctx *c, float tw, float th, const floa
     int rc = rebuild_tables(c);
     if (rc) return rc;
     if (c->tile_mode != TILES_DEVICE || c->grid_tw != tw || c->grid_th != th || c->grid_n != c->n) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((rc = prepare_tile_grid(c, tw, th))) return rc;
+        if ((rc = prepare_tile_grid(c, tw, th))) return rc; // waits for frames in flight (quiesce)
     }
     if (memcmp(c->view, view, 16 * sizeof(float))) c->reset_seq = c->frame_seq;
     memcpy(c->view, view, 16 * sizeof(float));
@@ -865,7 +891,7 @@ int vrt_hip_set_plane(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float *xs, c
     if (!w || !h || !xs || !ys || !zs) return fail(c, VRT_HIP_ERR_INVALID, "set_plane: bad argument");
     const size_t n = (size_t)w * h;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc = quiesce(c); if (rc) return rc; }
     HIPCHK(c, c->xs.reserve(n)); HIPCHK(c, c->ys.reserve(n)); HIPCHK(c, c->zs.reserve(n));
     HIPCHK(c, hipMemcpy(c->xs.p, xs, n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->ys.p, ys, n * 4, hipMemcpyHostToDevice));
@@ -889,49 +915,12 @@ int vrt_hip_set_camera(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float pos[3
     return VRT_HIP_OK;
 }
 
-// glm::inverse(mat4) (func_matrix.inl, compute_inverse<4, 4>: cofactor expansion), float, in glm's order of operations
-// and unfused -- the reference's projection plane is inverse(view) * point (camera.cpp:60-69), and its rays are only
-// reproduced bit for bit if the inverse is
-static void glm_inverse4(const float a[16], float out[16])
-{
-#pragma clang fp contract(off)
-#define M(c, r) a[(c) * 4 + (r)]
-    const float c00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3), c02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3),
-                c03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
-    const float c04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3), c06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3),
-                c07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
-    const float c08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2), c10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2),
-                c11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
-    const float c12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3), c14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3),
-                c15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
-    const float c16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2), c18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2),
-                c19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
-    const float c20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1), c22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1),
-                c23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
-    const float f0[4] = { c00, c00, c02, c03 }, f1[4] = { c04, c04, c06, c07 }, f2[4] = { c08, c08, c10, c11 };
-    const float f3[4] = { c12, c12, c14, c15 }, f4[4] = { c16, c16, c18, c19 }, f5[4] = { c20, c20, c22, c23 };
-    const float v0[4] = { M(1, 0), M(0, 0), M(0, 0), M(0, 0) }, v1[4] = { M(1, 1), M(0, 1), M(0, 1), M(0, 1) };
-    const float v2[4] = { M(1, 2), M(0, 2), M(0, 2), M(0, 2) }, v3[4] = { M(1, 3), M(0, 3), M(0, 3), M(0, 3) };
-    const float sa[4] = { +1, -1, +1, -1 }, sb[4] = { -1, +1, -1, +1 };
-    float inv[16];
-    for (int i = 0; i < 4; ++i) {
-        inv[0 * 4 + i] = (v1[i] * f0[i] - v2[i] * f1[i] + v3[i] * f2[i]) * sa[i];
-        inv[1 * 4 + i] = (v0[i] * f0[i] - v2[i] * f3[i] + v3[i] * f4[i]) * sb[i];
-        inv[2 * 4 + i] = (v0[i] * f1[i] - v1[i] * f3[i] + v3[i] * f5[i]) * sa[i];
-        inv[3 * 4 + i] = (v0[i] * f2[i] - v1[i] * f4[i] + v2[i] * f5[i]) * sb[i];
-    }
-    const float d0 = M(0, 0) * inv[0], d1 = M(0, 1) * inv[4], d2 = M(0, 2) * inv[8], d3 = M(0, 3) * inv[12];
-    const float one_over_det = 1.f / ((d0 + d1) + (d2 + d3));
-    for (int i = 0; i < 16; ++i) out[i] = inv[i] * one_over_det;
-#undef M
-}
-
 int vrt_hip_set_camera_view(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float view[16])
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     if (!w || !h || !view) return fail(c, VRT_HIP_ERR_INVALID, "set_camera_view: bad argument");
     float inv[16];
-    glm_inverse4(view, inv);
+    vrt_hip_mat4_inverse(view, inv); // glm::inverse in glm's order, unfused (csrc/vrt_host_camera.cpp)
     for (int i = 0; i < 16; ++i)
         if (!std::isfinite(inv[i])) return fail(c, VRT_HIP_ERR_INVALID, "set_camera_view: the view matrix is singular");
     if (c->w != w || c->h != h || c->plane_mode || !c->view_mode || memcmp(c->inv_view, inv, sizeof inv))
@@ -1005,8 +994,9 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
     if (c->stats_on) {
-        unsigned long long st[12];
+        unsigned long long st[16];
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
+        c->last.lane_pairs = st[12];
         c->last.dense_busy_frac = (st[11] && st[9] > st[8]) ? (double)st[10] / ((double)st[11] * (double)(st[9] - st[8])) : 0.0;
         c->last.shaded_blocks = st[5] + st[6];
         c->last.dense_blocks = st[6];
@@ -1176,6 +1166,26 @@ int vrt_hip_transmittance(vrt_hip_ctx *c, const float o[3], const float n[3], co
     return VRT_HIP_OK;
 }
 
+int vrt_hip_transmittance_rays(vrt_hip_ctx *c, size_t nrays, const float *origins, const float *dirs, const float *s,
+                               float *T_out)
+{
+    if (!c || (nrays && (!origins || !dirs || !s || !T_out))) return VRT_HIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+    DevBuf<float> d_o, d_d, ds, dT;
+    if ((rc = upload(c, d_o, origins, nrays * 3))) return rc;
+    if ((rc = upload(c, d_d, dirs, nrays * 3))) return rc;
+    if ((rc = upload(c, ds, s, nrays))) return rc;
+    HIPCHK(c, dT.reserve(nrays));
+    launch_transmittance_rays(tables(c), d_o.p, d_d.p, ds.p, nrays, dT.p, c->exp_kind, c->erf_kind, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nrays) HIPCHK(c, hipMemcpy(T_out, dT.p, nrays * 4, hipMemcpyDeviceToHost));
+    d_o.release(); d_d.release(); ds.release(); dT.release();
+    return VRT_HIP_OK;
+}
+
 int vrt_hip_transmittance_step(vrt_hip_ctx *c, const float o[3], const float n[3], const float *s, size_t ns, float delta,
                                float *T_out)
 {
@@ -1299,7 +1309,6 @@ int vrt_hip_get_kernel_timing(vrt_hip_ctx *c, double *render_ms, double *dense_m
 int vrt_hip_get_stats(vrt_hip_ctx *c, vrt_hip_stats *out)
 {
     if (!c || !out) return VRT_HIP_ERR_INVALID;
-    c->last.slow_path_total = c->h_fb ? c->h_fb[1] : 0;
     *out = c->last;
     return VRT_HIP_OK;
 }

@@ -53,14 +53,14 @@ struct CellGrid {
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
                                      // LDS slots: it hands them to the dense kernel, which runs after it
     uint32_t dense_threshold;        // a cell whose list is longer than this goes to the dense queue
-    // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame, [1] = running count of blocks the
-    // one-wave kernel had to shade through its slow path, [2] = items the dense kernel found, [3] = sequence number
-    // of the frame that wrote [0].  The host reads it
-    // frames later to decide whether the (mostly empty, ~12 us) dense launch can be dropped; `no_dense` tells the
-    // one-wave kernel that no dense kernel follows, so it must shade everything itself.
+    // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame (written by the one-wave kernel),
+    // [2] = items (blocks) the dense kernel found in its queues, [3] = sequence number of the frame that wrote [2]
+    // ([1] unused).  The host reads it frames later to SIZE the dense launch: a frame that is expected to have nothing
+    // for it gets a handful of workgroups instead of one per CU and no queue sort.  Which kernel shades a block never
+    // depends on it.
     uint32_t *feedback;
-    uint32_t frame_seq;              // written to feedback[3] after feedback[0]: which frame the report is from
-    int no_dense;
+    uint32_t frame_seq;
+    int dense_is_sorted;             // the dense kernel reads dense_sorted (order_dense_kernel ran) or dense (it did not)
     // Work queues of the one-wave kernel: a wave's first block is static (item = wave), the blocks beyond the grid size
     // are pulled from RQ_N counters RQ_STRIDE words apart (item G + q + RQ_N*m is the m-th of queue q).  `rq` is this
     // launch's set (zero on entry), `rq_next` the other set, which this launch clears for the next one.
@@ -97,6 +97,7 @@ struct RenderTarget {
     int cleared;              // empty cells were already cleared by the list kernel of this frame
     unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
                                // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
+                               // [6]=dense blocks [7]=table blocks [8..11]=dense workgroup timeline [12]=sum over rays of (lane list length)^2
     unsigned long long *timeline; // nullable diagnostics: 4 wall_clock64 stamps + the hardware id per one-wave work item (5 words)
 };
 
@@ -155,6 +156,8 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);
 // point queries
 void launch_transmittance(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
                           float *d_T, int exp_kind, int erf_kind, hipStream_t st);
+void launch_transmittance_rays(const SceneTables &s, const float *d_origins, const float *d_dirs, const float *d_s,
+                               size_t nrays, float *d_T, int exp_kind, int erf_kind, hipStream_t st);
 void launch_transmittance_step(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
                                float delta, float *d_T, hipStream_t st);
 void launch_density(const SceneTables &s, const float *d_pts, size_t npts, float *d_D, hipStream_t st);

@@ -468,10 +468,8 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     const uint32_t n_active = *C.n_active, n_dense_cells = *C.n_dense;
     if (C.feedback && wave == 0 && lane == 0) {
         __hip_atomic_store(&C.feedback[0], n_dense_cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&C.feedback[3], C.frame_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // without a dense kernel behind it this kernel also walks the dense cells (slow path for what does not fit)
-    const uint32_t n_shade = (n_active + (C.no_dense ? n_dense_cells : 0u)) * 16u;
+    const uint32_t n_shade = n_active * 16u; // the dense cells belong to the 16-waves-per-block kernel behind this one
 
     // ---- clear the cells nothing can reach (4 B per ray: the only HBM traffic of most of the frame) ----
     const uint32_t zero_px = (O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
@@ -525,7 +523,7 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
     for (uint32_t item = wave; item < n_shade; item = next_item()) {
         const unsigned long long tl0 = O.timeline ? wall_clock64() : 0ull; // diagnostics (VRT_HIP_TIMELINE runs only)
         const uint32_t ci = item >> 4;
-        const uint32_t cell = ci < n_active ? C.active[ci] : C.dense[ci - n_active];
+        const uint32_t cell = C.active[ci];
         const uint32_t bi = item & 15u;
         const BlockPos p = block_of(T, C, O, cell, bi, lane);
         if (!p.inside) continue;
@@ -592,16 +590,12 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
             fast = __ballot(nl > PL) == 0ull;
         }
         __syncthreads();
-        if (!fast && !C.no_dense) { // hand the block to the 16-waves-per-block kernel that runs after this one
+        if (!fast) {
+            // Per-ray lists that outgrow LDS: the block goes to the 16-waves-per-block kernel, which ALWAYS runs after
+            // this one.  Which kernel shades a block is a function of the block alone (the two kernels sum in different
+            // orders), so the image does not depend on launch heuristics: the host only chooses how LARGE the dense
+            // launch is (vrt_hip_api.cpp, render_common).
             if (lane == 0) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | bi;
-            continue;
-        }
-        if (!fast) { // nobody to hand it to: stream the list through scalar loads (any length, one wave)
-            if (C.feedback && lane == 0) __hip_atomic_fetch_add(&C.feedback[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (O.stats && lane == 0) { atomicAdd(&O.stats[2], 1ull); atomicAdd(&O.stats[5], 1ull); }
-            float Lr, Lg, Lb, La;
-            shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La);
-            write_block(Lr, Lg, Lb, La, valid, out);
             continue;
         }
         if (O.stats && lane == 0) {
@@ -616,7 +610,10 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
             unsigned long long tot = nl;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((int)tot, off, 64);
-            if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); }
+            unsigned long long sq = (unsigned long long)nl * nl; // this ray's (emitter, absorber) pairs: 5 erf terms each
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += (unsigned long long)(uint32_t)__shfl_xor((int)sq, off, 64);
+            if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); atomicAdd(&O.stats[12], sq); }
         }
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
         float Lr, Lg, Lb, La;
@@ -673,7 +670,11 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
     constexpr float SAT = erf_saturation<ERF>();
     constexpr float SAT_M = SAT + 1e-3f; // the range bounds are re-associated forms of the arguments: keep a margin
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
-    if (C.feedback && blockIdx.x == 0 && tid == 0) C.feedback[2] = n_items;
+    if (C.feedback && blockIdx.x == 0 && tid == 0) { // launch feedback: how much this frame had for this kernel
+        __hip_atomic_store(&C.feedback[2], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&C.feedback[3], C.frame_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const uint32_t *dense_queue = C.dense_is_sorted ? C.dense_sorted : C.dense;
     uint32_t *scratch = C.scratch + (size_t)blockIdx.x * C.cstride;
     const unsigned long long t_start = O.stats ? wall_clock64() : 0ull;
 
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
             break;
         }
         uint32_t cell, bi;
-        if (item < n_dense16) { cell = C.dense_sorted[item >> 4]; bi = item & 15u; }
+        if (item < n_dense16) { cell = dense_queue[item >> 4]; bi = item & 15u; }
         else { const uint32_t packed = C.overflow[item - n_dense16]; cell = packed >> 4; bi = packed & 15u; }
         const BlockPos p = block_of(T, C, O, cell, bi, lane);
         if (!p.inside) continue;
@@ -907,7 +908,11 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t npix = (uint64_t)R.width * R.height;
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
-    if (C.feedback && blockIdx.x == 0 && tid == 0) C.feedback[2] = n_items;
+    if (C.feedback && blockIdx.x == 0 && tid == 0) {
+        __hip_atomic_store(&C.feedback[2], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&C.feedback[3], C.frame_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const uint32_t *dense_queue = C.dense_is_sorted ? C.dense_sorted : C.dense;
 
     for (;;) {
         __syncthreads(); // everyone is done with the previous item's LDS
@@ -916,7 +921,7 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
         const uint32_t item = s_item;
         if (item >= n_items) break;
         uint32_t cell, bi;
-        if (item < n_dense16) { cell = C.dense_sorted[item >> 4]; bi = item & 15u; }
+        if (item < n_dense16) { cell = dense_queue[item >> 4]; bi = item & 15u; }
         else { const uint32_t packed = C.overflow[item - n_dense16]; cell = packed >> 4; bi = packed & 15u; }
         const BlockPos p = block_of(T, C, O, cell, bi, lane);
         if (!p.inside) continue;
@@ -1591,6 +1596,49 @@ __global__ void transmittance_kernel(SceneTables S, float ox, float oy, float oz
     }
     T_out[k] = vexp<EXP>(T);
 }
+// The same per ray: ray k has its own origin, direction and sample point -- broadcast_transmittance (rt.h:102-127),
+// lane = ray.  The arithmetic is transmittance_kernel's (exact divides; the reference's rcp14 estimates are not
+// reproduced).
+template <int EXP, int ERF>
+__global__ void transmittance_rays_kernel(SceneTables S, const float *origins, const float *dirs, const float *s_in,
+                                          size_t nrays, float *T_out)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nrays) return;
+    const float ox = origins[3 * k], oy = origins[3 * k + 1], oz = origins[3 * k + 2];
+    const float nx = dirs[3 * k], ny = dirs[3 * k + 1], nz = dirs[3 * k + 2];
+    const float s = s_in[k];
+    float T = 0.f;
+    for (uint32_t q = 0; q < S.n; ++q) {
+        const float4 g = S.mu_sig[q];
+        const float mag = S.gD[q].z;
+        const float cx = sub_ref(g.x, ox), cy = sub_ref(g.y, oy), cz = sub_ref(g.z, oz);
+        const float mu_bar = dot3_ref(cx, cy, cz, nx, ny, nz);
+        const float oc_sq = dot3_ref(cx, cy, cz, cx, cy, cz);
+        const float inv_2_sigma2 = 1.f / mul_ref(mul_ref(2.f, g.w), g.w);
+        const float c_bar = mul_ref(mag, vexp<EXP>(-mul_ref(sub_ref(oc_sq, mul_ref(mu_bar, mu_bar)), inv_2_sigma2)));
+        const float sqrt_2_sig = mul_ref(SQRT_2, g.w);
+        const float mu_bar_n = mu_bar / sqrt_2_sig;
+        const float s_n = s / sqrt_2_sig;
+        const float term = mul_ref(mul_ref(mul_ref(g.w, c_bar), INV_SQRT_2_PI), sub_ref(verf<ERF>(-mu_bar_n), verf<ERF>(sub_ref(s_n, mu_bar_n))));
+        T = add_ref(T, term);
+    }
+    T_out[k] = vexp<EXP>(T);
+}
+template <int EXP, int ERF>
+static void launch_transmittance_rays_t(const SceneTables &s, const float *d_o, const float *d_n, const float *d_s, size_t nrays,
+                                        float *d_T, hipStream_t st)
+{
+    hipLaunchKernelGGL((transmittance_rays_kernel<EXP, ERF>), dim3((uint32_t)((nrays + 63) / 64)), dim3(64), 0, st, s, d_o,
+                       d_n, d_s, nrays, d_T);
+}
+void launch_transmittance_rays(const SceneTables &s, const float *d_o, const float *d_n, const float *d_s, size_t nrays,
+                               float *d_T, int exp_kind, int erf_kind, hipStream_t st)
+{
+    if (!nrays) return;
+    VRT_DISPATCH_EXP_ERF(launch_transmittance_rays_t, s, d_o, d_n, d_s, nrays, d_T, st);
+}
+
 template <int EXP, int ERF>
 static void launch_transmittance_t(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,
                                    float *d_T, hipStream_t st)

@@ -16,29 +16,37 @@
 #include "../../include/vrt/vrt.hpp"
 #include "png_writer.hpp"
 
-#define HELP_MSG "Usage: volumetric-ray-tracer [options]\n"\
-    "\nOptions:\n"\
-    "\t--help:                                 Show this help message.\n"\
-    "\t--file <file>, -f <file>:               Load gaussians as verticies from <file> (.obj).\n"\
-    "\t--output <file>, -o <file>:             Write image to <file> as in PNG format.\n"\
-    "\t--grid <dim=4>, -g <dim=4>:             Render a grid of <dim>x<dim> gaussians.\n"\
-    "\t--width <width>, -w <width>:            Set image width to <width>. Set height to <width> too if --height is not set.\n"\
-    "\t--height <height>, -h <height>:         Set image height to <height>. Set width to <height> too if --width is not set\n"\
-    "\t--with-threads <count>, -t <count>:     Accepted for compatibility; the GPU grid replaces the thread pool.\n"\
-    "\t--quiet, -q:                            Accepted for compatibility; there is no viewer, -q is always on.\n"\
-    "\t--frames <count>:                       Render <count> frames.\n"\
-    "\t--tiles <count>:                        Split the image into <count> tiles vertically and horizontally.\n"\
-    "\t--rotation <rot>, -r <rot>:             Changes the viewing angle by <rot>/<frames> every frame.\n"\
-    "\t--initial-rotation <rot>, -i <rot>:     Sets the initial rotation to <rot>.\n"\
-    "\t--camaera-offset <offset>, -c <offset>: Set the position of the camera along the Z-Axis to <offset>.\n"\
-    "\t--focal-length <focal-length>:          Set the focal length of the camera to <focal-length>.\n"\
-    "\t--mode <mode>, -m <mode>:               Set the rendering mode to <mode> (1-4 without, 5-8 with tiling;\n"\
-    "\t                                        selects the packing convention and Exp/Erf pair of that mode).\n"\
-    "\t--plane-arrays:                         Feed the projection-plane arrays like the reference (default: in-kernel rays).\n"\
-    "\t--cull-eps <eps>:                       Culling threshold (default 1e-9; 0 = the reference's full sum).\n"\
-    "\t--table-step <step>:                    Opt-in approximation for dense scenes: interpolate the transmittance along\n"\
-    "\t                                        each ray from 160 nodes no farther apart than <step>*sqrt2*sigma (0 = off,\n"\
-    "\t                                        the default; 0.12 keeps the radiance within 1e-5 on the test objects).\n"
+// Own wording; the flag set (names, short forms, defaults) is the reference's (main.cpp:28-52, 75-91) because scripts
+// written for it (runtimes.sh, gen-gif.sh) must keep working.
+static const char *const HELP_MSG =
+    "volumetric-ray-tracer (MI355X build) -- volumetric Gaussian renderer, quiet path of the reference CLI\n"
+    "\n"
+    "scene\n"
+    "  -g, --grid [N]            N x N Gaussians on the plane z = 1 (N defaults to 4); the scene when no file is given\n"
+    "  -f, --file PATH           one Gaussian per vertex of a Wavefront OBJ file; wins over --grid\n"
+    "image\n"
+    "  -w, --width PX            image width  (256); also the height unless --height is given\n"
+    "  -h, --height PX           image height (256); also the width unless --width is given\n"
+    "  -o, --output PATH         write the frame as PNG; with --frames N > 1: <stem>_<k>.<ext>, k = 1..N\n"
+    "      --tiles N             N x N image tiles, each rendered with its own Gaussian subset (16)\n"
+    "  -m, --mode 1..8           rendering mode of the reference: 1-4 untiled, 5-8 tiled; picks the pixel packing and\n"
+    "                            the exp/erf pair of that mode (8 = tiled, SIMD-over-pixels semantics; the default)\n"
+    "camera and animation\n"
+    "  -c, --camera-offset Z     camera starts at (0, 0, Z) looking along +z (-4)\n"
+    "      --focal-length F      distance from the camera to the projection plane (1)\n"
+    "  -i, --initial-rotation D  orbit the camera D degrees about the y axis before the first frame (0)\n"
+    "      --frames N            render N frames (1); prints the average frame time instead of one time\n"
+    "  -r, --rotation D          total orbit angle over all frames, i.e. D/N degrees per frame (360)\n"
+    "accepted for compatibility, no effect here\n"
+    "  -t, --with-threads N      CPU worker threads of the reference; the GPU grid takes their place\n"
+    "  -q, --quiet               the reference's 'no viewer' switch; this build never opens one\n"
+    "this build only\n"
+    "      --plane-arrays        upload per-pixel projection-plane points like the reference instead of generating\n"
+    "                            rays in the kernel (same image, 12 more bytes per ray)\n"
+    "      --cull-eps E          contributions below E are skipped (1e-9); 0 evaluates the reference's full sum\n"
+    "      --table-step S        approximate mode for dense scenes: tabulate the transmittance along each ray at 160\n"
+    "                            nodes at most S*sqrt(2)*sigma apart (0 = off; 0.12 stays within 1e-5 on the test objects)\n"
+    "      --help                this text\n";
 
 struct cmd_args_t { // main.cpp:54-184
     u64 w = (u64)-1, h = (u64)-1;

@@ -6,11 +6,14 @@ Mirrors (reference paths relative to /root/reference/src):
   read_obj        vrt/gaussians-from-file.cpp:7-44
   Camera          vrt/camera.cpp:7-71 (turn / update), orbit step main.cpp:330-334
 """
+import ctypes as C
+
 import numpy as np
 
 GAUSSIAN = np.dtype([("albedo", np.float32, 4), ("mu", np.float32, 4), ("sigma", np.float32),
                      ("magnitude", np.float32)])
 f32 = np.float32
+_f32p = C.POINTER(C.c_float)
 
 
 def grid_scene(grid_dim):
@@ -57,62 +60,55 @@ def read_obj(path):
     return g
 
 
-def _normalize(v):
-    v = v.astype(f32)
-    return (v * (f32(1) / np.sqrt(np.dot(v, v).astype(f32)))).astype(f32)
+class _CCamera(C.Structure):
+    """vrt_hip_camera (include/vrt_hip.h)."""
+    _fields_ = [("position", C.c_float * 3), ("front", C.c_float * 3), ("up", C.c_float * 3),
+                ("world_up", C.c_float * 3), ("right", C.c_float * 3), ("view", C.c_float * 16),
+                ("focal_length", C.c_float), ("w", C.c_uint64), ("h", C.c_uint64)]
+
+
+def _L():
+    from . import lib
+    return lib()
 
 
 class Camera:
-    """yaw/pitch camera of vrt/camera.cpp.  Rays leave `position` through the plane
-    position + x*right + y*up - focal*front  (the closed form of camera.cpp:52,60-69)."""
+    """yaw/pitch camera of vrt/camera.cpp: a view over the library's vrt_hip_camera (csrc/vrt_host_camera.cpp), which
+    evaluates lookAt -> translate -> inverse -> mat4*vec4 in glm's order of operations, unfused -- the view matrix
+    and the plane points are the reference's to the last bit (numpy's own cos/sin and sums are not: a last-bit
+    difference in a ray shows up as up to 5e-4 of radiance for small sigma)."""
 
-    def __init__(self, position, w, h, yaw=-90.0, pitch=0.0, focal=1.0, up=(0, 1, 0)):
-        self.position = np.asarray(position, f32)
-        self.world_up = np.asarray(up, f32)
-        self.focal = f32(focal)
+    def __init__(self, position, w, h, yaw=-90.0, pitch=0.0, focal=1.0, up=(0, 1, 0), front=(0, 0, 1)):
+        self._c = _CCamera()
         self.w, self.h = int(w), int(h)
-        self.turn(yaw, pitch)
+        p, u, f = (np.ascontiguousarray(v, f32) for v in (position, up, front))
+        _L().vrt_hip_camera_init(C.byref(self._c), p.ctypes.data_as(_f32p), u.ctypes.data_as(_f32p),
+                                 f.ctypes.data_as(_f32p), float(yaw), float(pitch), self.w, self.h, float(focal))
+
+    position = property(lambda self: np.array(self._c.position[:], f32))
+    front = property(lambda self: np.array(self._c.front[:], f32))
+    right = property(lambda self: np.array(self._c.right[:], f32))
+    up = property(lambda self: np.array(self._c.up[:], f32))
+    focal = property(lambda self: f32(self._c.focal_length))
 
     def turn(self, yaw, pitch=0.0):
-        p = min(max(float(pitch), -89.0), 89.0)
-        ry, rp = np.radians(f32(yaw), dtype=f32), np.radians(f32(p), dtype=f32)
-        front = np.array([np.cos(ry) * np.cos(rp), np.sin(rp), np.sin(ry) * np.cos(rp)], f32)
-        self.front = _normalize(front)
-        self.right = _normalize(np.cross(self.front, self.world_up).astype(f32))
-        self.up = _normalize(np.cross(self.right, self.front).astype(f32))
+        _L().vrt_hip_camera_turn(C.byref(self._c), float(yaw), float(pitch), 1)
 
     @property
     def view(self):
         """translate(lookAtRH(pos, pos+front, up), focal*front), column-major float[16] (glm layout)."""
-        s, u, f, e = self.right, self.up, self.front, self.position
-        m = np.zeros((4, 4), f32)  # m[col][row]
-        m[0][0], m[1][0], m[2][0] = s
-        m[0][1], m[1][1], m[2][1] = u
-        m[0][2], m[1][2], m[2][2] = -f
-        m[3][0] = -np.dot(s, e)
-        m[3][1] = -np.dot(u, e)
-        m[3][2] = np.dot(f, e)
-        m[3][3] = 1
-        t = (self.focal * f).astype(f32)
-        m[3] = m[0] * t[0] + m[1] * t[1] + m[2] * t[2] + m[3]
-        return m.ravel().copy()
+        return np.array(self._c.view[:], f32)
 
     def plane(self):
-        """The three w*h projection-plane arrays (camera.cpp:60-69) via the closed form."""
-        x = (f32(-1) + np.arange(self.w, dtype=f32) / f32(self.w / 2.0)).astype(f32)
-        y = (f32(-1) + np.arange(self.h, dtype=f32) / f32(self.h / 2.0)).astype(f32)
-        base = (self.position - self.focal * self.front).astype(f32)
-        pts = base[None, None, :] + x[None, :, None] * self.right[None, None, :] + y[:, None, None] * self.up[None, None, :]
-        pts = pts.astype(f32)
-        return (np.ascontiguousarray(pts[..., 0]).ravel(), np.ascontiguousarray(pts[..., 1]).ravel(),
-                np.ascontiguousarray(pts[..., 2]).ravel())
+        """The three w*h projection-plane arrays, inverse(view) * (x, y, 0, 1) per pixel (camera.cpp:60-69)."""
+        xs, ys, zs = (np.empty(self.w * self.h, f32) for _ in range(3))
+        _L().vrt_hip_camera_plane(C.byref(self._c), xs.ctypes.data_as(_f32p), ys.ctypes.data_as(_f32p),
+                                  zs.ctypes.data_as(_f32p))
+        return xs, ys, zs
 
     def orbit(self, deg):
-        """main.cpp:330-334: position = rotate(I, radians(deg), +Y) * position."""
-        a = np.radians(f32(deg), dtype=f32)
-        c, s = np.cos(a), np.sin(a)
-        x, y, z = self.position
-        self.position = np.array([c * x + s * z, y, -s * x + c * z], f32)
+        """main.cpp:252, 330: position = rotate(I, radians(deg), +Y) * position (the caller then turns)."""
+        _L().vrt_hip_camera_orbit(C.byref(self._c), float(deg))
 
 
 def cli_camera(w, h, camera_offset=-4.0, focal=1.0, initial_rot=0.0):
@@ -122,3 +118,11 @@ def cli_camera(w, h, camera_offset=-4.0, focal=1.0, initial_rot=0.0):
     angle = f32(-90.0) - f32(initial_rot)
     cam.turn(angle, 0.0)
     return cam, angle
+
+
+def orbit_step(cam, angle, deg):
+    """One step of the frame loop's orbit (main.cpp:329-334).  Returns the new angle."""
+    cam.orbit(deg)
+    angle = f32(f32(angle) - f32(deg))
+    cam.turn(angle, 0.0)
+    return angle

@@ -4,9 +4,11 @@
 
 One long-lived context receives a random sequence of state changes (scene, image size, rays by plane arrays / view
 matrix, tiling on the device / by the caller / none, Exp/Erf variant, cull_eps, table mode, shard) and renders after each
-through a randomly chosen entry point, several frames back to back without waiting now and then.  Every image must be
-bit-identical to what a FRESH context configured from scratch with the same state renders: anything else is state that
-leaked from an earlier configuration."""
+through a randomly chosen entry point, several frames back to back without waiting now and then -- and sometimes
+("nosync") on a side stream WITHOUT waiting for them before the next state change is applied: the library itself has
+to wait for frames in flight before it rewrites tables, lists or plane arrays they read (quiesce() in
+csrc/vrt_hip_api.cpp).  Every image must be bit-identical to what a FRESH context configured from scratch with the same
+state renders: anything else is state that leaked from an earlier configuration, or a frame that saw a later one."""
 import os
 import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -67,6 +69,25 @@ def apply(r, st, what=None):
             r.set_tiles(O.tile_gaussians(2.0 / tn, 2.0 / tn, st["g"], st["view"]))
 
 
+SIDE = torch.cuda.Stream()
+
+
+def render_nosync(r, st):
+    """Enqueue frames on a side stream and return WITHOUT waiting: (buffer, shape is read later)."""
+    w, h = st["w"], st["h"]
+    s = SIDE.cuda_stream
+    out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # the buffer's zero fill (default stream) is done; nothing else is waited for below
+    if st["tiles"][0] == "device":
+        f = r.frame_call(2.0 / st["tiles"][1], 2.0 / st["tiles"][1], st["view"], st["origin"], PACK)
+        for _ in range(int(rng.integers(1, 4))):
+            f(out.data_ptr(), s)
+    else:
+        for _ in range(int(rng.integers(1, 4))):
+            r.render_device(st["origin"], PACK, out.data_ptr(), 0, s)
+    return out
+
+
 def render(r, st, how):
     w, h = st["w"], st["h"]
     s = torch.cuda.current_stream().cuda_stream
@@ -95,6 +116,7 @@ def render(r, st, how):
 A = pkg.Renderer(0)
 apply(A, state)
 bad = 0
+pending = None   # (device buffer still being rendered into, expected image, description)
 for step in range(nsteps):
     op = rng.choice(["g", "camera", "rays", "tiles", "opt", "table", "shard", "none"], p=[.12, .2, .08, .2, .12, .08, .1, .1])
     if op == "g":
@@ -113,16 +135,33 @@ for step in range(nsteps):
     elif op == "shard":
         world = int(rng.choice([1, 1, 2, 3, 8])); state["shard"] = (int(rng.integers(world)), world)
     if op != "none":
-        apply(A, state, op)
-    how = str(rng.choice(["sync", "device", "async"]))
-    got = render(A, state, how)
+        apply(A, state, op)          # with frames of the PREVIOUS state possibly still in flight (pending)
+    if pending is not None:
+        buf, want_prev, desc = pending
+        torch.cuda.synchronize()
+        got_prev = buf.cpu().numpy().view(np.uint32)
+        ok_prev = got_prev.shape == want_prev.shape and bool((got_prev == want_prev).all())
+        bad += not ok_prev
+        print(f"        frames left in flight across '{op}' ({desc}): {'ok' if ok_prev else 'MISMATCH  <-- FAIL'}", flush=True)
+        pending = None
+    how = str(rng.choice(["sync", "device", "async", "nosync"]))
+    if how == "nosync" and state["shard"][1] > 1:
+        how = "async"
     B = pkg.Renderer(0)
     apply(B, state)
     want = render(B, state, "sync" if how == "sync" else "device")
     B.close()
-    same = got.shape == want.shape and bool((got == want).all())
+    if how == "nosync":
+        pending = (render_nosync(A, state), want, f"step {step}")
+        same = True                  # judged after the next state change
+    else:
+        got = render(A, state, how)
+        same = got.shape == want.shape and bool((got == want).all())
     if not same:
         bad += 1
     print(f"step {step}: {op:7s} -> n={len(state['g'])} {state['w']}x{state['h']} rays={state['rays']} tiles={state['tiles']} opt={state['opt']} "
           f"table={state['table']} shard={state['shard']} via {how}: {'ok' if same else 'MISMATCH  <-- FAIL'}", flush=True)
+if pending is not None:
+    torch.cuda.synchronize()
+    bad += not bool((pending[0].cpu().numpy().view(np.uint32) == pending[1]).all())
 print("mismatches:", bad)

@@ -62,26 +62,63 @@ def test_host_scene_matches_oracle(pkg, oracle):
         assert np.abs(a["albedo"] - b["albedo"]).max() <= 1.2e-7
 
 
-def test_host_camera_matches_oracle(pkg, oracle):
+def _same_camera(pc, oc, oracle, what):
+    for f in ("position", "front", "right", "up"):
+        np.testing.assert_array_equal(getattr(pc, f), np.array(getattr(oc, f)[:], np.float32), err_msg=f"{what} {f}")
+    np.testing.assert_array_equal(pc.view, oracle.camera_view(oc), err_msg=f"{what} view")
+    for got, ref, ax in zip(pc.plane(), oracle.camera_plane(oc), "xyz"):
+        np.testing.assert_array_equal(got, ref, err_msg=f"{what} plane {ax}")
+
+
+def test_host_camera_is_the_oracle_camera_bit_for_bit(pkg, oracle):
+    """camera.cpp:7-71 + main.cpp:247-255, 330-334: the product's camera (library arithmetic in glm's order) against
+    the oracle's restatement -- BIT equality of basis, view matrix and every plane point, at rotated poses, other focal
+    lengths / offsets / aspect ratios, and along an orbit.  (A last-bit difference in a ray is up to 5e-4 of radiance
+    for small sigma; a tolerance here would hide exactly that.)"""
     from sgrt_amd import scene
-    for rot in (0.0, 20.0, 123.0, 359.0):
-        pc, pa = scene.cli_camera(32, 32, initial_rot=rot)
-        oc, oa = oracle.cli_camera(32, 32, initial_rot=rot)
-        assert abs(float(pa) - float(oa[0])) <= 1e-4
-        for f in ("position", "front", "right", "up"):
-            assert np.abs(getattr(pc, f) - np.array(getattr(oc, f)[:])).max() <= 1e-6, (rot, f)
-        assert np.abs(pc.view - oracle.camera_view(oc)).max() <= 2e-6
-        got = np.stack(pc.plane(), -1)
-        ref = np.stack(oracle.camera_plane(oc), -1)
-        assert np.abs(got - ref).max() <= 3e-6
-    # orbit loop of main.cpp:330-334, 36 frames of 10 degrees: incremental float rotation stays on the circle
-    pc, ang = scene.cli_camera(8, 8)
-    oc, oa = oracle.cli_camera(8, 8)
-    for _ in range(36):
-        pc.orbit(10.0); ang = np.float32(ang - np.float32(10.0)); pc.turn(ang, 0.0)
-        oracle.orbit_step(oc, oa, 10.0)
-    assert np.abs(pc.position - np.array(oc.position[:])).max() <= 2e-5
-    assert np.abs(pc.position - np.array([0, 0, -4])).max() <= 1e-4
+    for rot in (0.0, 20.0, 33.0, 47.0, 123.0, 359.0):
+        pc, pa = scene.cli_camera(32, 24, initial_rot=rot)
+        oc, oa = oracle.cli_camera(32, 24, initial_rot=rot)
+        assert np.float32(pa) == oa[0]
+        _same_camera(pc, oc, oracle, f"rot {rot}")
+    for off, focal in ((-4.0, 1.0), (-2.5, 0.7), (-9.0, 2.25)):
+        pc, _ = scene.cli_camera(17, 40, camera_offset=off, focal=focal, initial_rot=61.0)
+        oc, _ = oracle.cli_camera(17, 40, camera_offset=off, focal=focal, initial_rot=61.0)
+        _same_camera(pc, oc, oracle, f"offset {off} focal {focal}")
+    # a pitched camera (the CLI never pitches; camera_t does)
+    pc = scene.Camera((0.3, -0.2, -4.0), 16, 16, yaw=-70.0, pitch=25.0, focal=1.5)
+    oc = oracle.camera((0.3, -0.2, -4.0), 16, 16, yaw=-70.0, pitch=25.0, focal=1.5)
+    _same_camera(pc, oc, oracle, "pitched")
+    # the orbit loop, 36 steps of 10 degrees and 360 steps of 1 degree (cfg5): every pose identical, not just the last
+    for steps, deg in ((36, 10.0), (360, 1.0)):
+        pc, ang = scene.cli_camera(8, 8)
+        oc, oa = oracle.cli_camera(8, 8)
+        for k in range(steps):
+            ang = scene.orbit_step(pc, ang, deg)
+            oracle.orbit_step(oc, oa, deg)
+            assert np.float32(ang) == oa[0]
+            _same_camera(pc, oc, oracle, f"orbit {deg} step {k}")
+        assert np.abs(pc.position - np.array([0, 0, -4])).max() <= 1e-4   # incremental float rotation stays on the circle
+
+
+def test_cxx_mirror_camera_is_the_oracle_camera_bit_for_bit(pkg, oracle, tmp_path):
+    """vrt::camera_t of include/vrt/vrt.hpp, compiled HERE with -O3 -ffast-math -march=native (the reference's own
+    flags, CMakeLists.txt:8 -- the worst case for a header): view matrix and plane arrays still equal the oracle's
+    bit for bit, because the arithmetic is the library's."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "host", "camera_dump.cpp")
+    exe = str(tmp_path / "camera_dump")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["g++", "-O3", "-ffast-math", "-march=native", "-std=c++17", "-I", os.path.join(ROOT, "include"), src,
+                           "-o", exe, "-L", libdir, "-lvrt_hip", f"-Wl,-rpath,{libdir}"])
+    for rot, steps in ((0.0, 0), (33.0, 0), (47.0, 3), (123.0, 0), (359.0, 2)):
+        out = subprocess.check_output([exe, "12", "10", str(rot), str(steps), "7.5"])
+        got = np.frombuffer(out, np.float32)
+        oc, oa = oracle.cli_camera(12, 10, initial_rot=rot)
+        for _ in range(steps):
+            oracle.orbit_step(oc, oa, 7.5)
+        ref = np.concatenate([np.array(oc.position[:], np.float32), oracle.camera_view(oc), *oracle.camera_plane(oc)])
+        np.testing.assert_array_equal(got, ref, err_msg=f"rot {rot} steps {steps}")
 
 
 def test_shard_table_partitions_the_frame(pkg):

@@ -58,9 +58,19 @@ def test_cpp_mirror_example_runs(tmp_path):
     p = run([os.path.join(BIN, "api_example")], tmp_path)
     assert p.returncode == 0, p.stderr
     lines = p.stdout.strip().splitlines()
-    assert lines[0] == "s, T, T_s, err, D" and len(lines) == 16
+    assert lines[0] == "s, T, T_s, err, D" and len(lines) == 21
     first = [float(v) for v in lines[1].split(",")]
     assert abs(first[1] - 1.0) < 0.2            # T near 1 for the sample point nearest the origin
     last = [float(v) for v in lines[13].split(",")]
     assert 0 < last[1] < first[1]               # transmittance decreases along the ray
     assert lines[14].startswith("radiance ") and lines[15].startswith("aborted: 0")
+    # broadcast_transmittance / broadcast_radiance (rt.h:102-127, 205-223): lane l of the W-wide call == the one-ray call
+    lanes = [ln for ln in lines if ln.startswith("lane ")]
+    assert len(lanes) == 4
+    for ln in lanes:
+        v = [float(x) for x in re.findall(r"[-+]?\d[-+0-9.e]*", ln.split(":", 1)[1])]
+        assert len(v) == 10 and v[0] == v[1] and v[2:6] == v[6:10], ln
+        assert 0 < v[0] <= 1.0001
+    # a tiles_t survives an untiled render and another scene's tiling (stale tiles_t rendered silently wrong)
+    m = re.fullmatch(r"tiles_t reuse: (\d+) pixels differ from the first tiled image \(untiled: (\d+), other scene: (\d+)\)", lines[-1])
+    assert m and int(m.group(1)) == 0 and int(m.group(2)) > 0 and int(m.group(3)) > 0, lines[-1]

@@ -557,9 +557,9 @@ def test_kernel_timing_modes(pkg, oracle, renderer):
 
 def test_frames_enqueued_back_to_back_with_a_moving_camera(pkg, oracle, renderer):
     """An orbit whose frames are enqueued without waiting (the CLI's --frames loop): the host runs many frames ahead of
-    the GPU, so the library's launch prediction (is the dense kernel needed?) must not act on reports of frames that
-    were rendered with another camera.  Every frame equals the one a waiting caller gets, and no block fell to the
-    one-wave kernel's streaming fallback."""
+    the GPU, and the library sizes its dense launch from reports of EARLIER frames.  Which kernel shades a block never
+    depends on those reports (only how many workgroups the dense launch gets), so every frame equals the one a waiting
+    caller gets, bit for bit -- including the views that do need the dense kernel."""
     import torch
     from sgrt_amd import scene
     w = h = 1024
@@ -568,13 +568,11 @@ def test_frames_enqueued_back_to_back_with_a_moving_camera(pkg, oracle, renderer
     pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
     st = torch.cuda.current_stream().cuda_stream
     cams = [scene.cli_camera(w, h, initial_rot=float(a))[0] for a in (0, 0, 0, 0, 20, 45, 60, 80, 100, 100, 100, 140)]
-    slow0 = renderer.stats()["slow_path_total"]
     bufs = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in cams]
     for cam, buf in zip(cams, bufs):                                   # no synchronisation inside this loop
         renderer.set_camera(w, h, cam.position, cam.right, cam.up, cam.front, float(cam.focal))
         renderer.frame_call(2 / 16, 2 / 16, cam.view, cam.position, pack)(buf.data_ptr(), st)
     torch.cuda.synchronize()
-    assert renderer.stats()["slow_path_total"] == slow0
     dense_seen = False
     for cam, buf in zip(cams, bufs):
         renderer.set_camera(w, h, cam.position, cam.right, cam.up, cam.front, float(cam.focal))

@@ -13,8 +13,22 @@ through gathers, so the raw value is a lower bound and 2x it an upper bound; bot
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha():
+    """Same identity bench.py computes: the summary is only used with the kernel sources it was taken with."""
+    h = hashlib.sha256()
+    for name in ("vrt_kernels.hip", "vrt_kernels.h", "vrt_device_math.h"):
+        with open(os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
 
 out = sys.argv[1]
 res = {}
@@ -34,6 +48,7 @@ w = 2048
 cal = res["build_tile_lists_kernel"]["WRITE_SIZE"]["empty_scene_bytes_per_launch"]
 summary = {
     "workload": "-g 64 -w 2048, tiles 16 (tools/pmc_workload.py)",
+    "kernel_source_sha": kernel_source_sha(),
     "write_size_calibration": {"expected_bytes_clear_only": w * w * 4, "measured_bytes_list_kernel_empty_scene": cal,
                                "ratio": cal / (w * w * 4)},
     "per_kernel": res,
