@@ -220,6 +220,11 @@ typedef struct {
     uint64_t table_blocks;   /* of the dense blocks, those shaded through the interpolation table (vrt_hip_set_table_step) */
     uint64_t lane_pairs;     /* sum over rays of (per-ray list length)^2: the (emitter, absorber) pairs the one-wave
                                 kernel has to evaluate, 5 erf terms each -- the ALGORITHMIC work of its pair loops    */
+    /* dense kernel: visits of an absorber by a chunk of 6 emitters (30 erf terms on every ray of the block when
+     * evaluated), split by what the exact saturation tests decided */
+    uint64_t dense_visits_full;   /* evaluated term by term                                              */
+    uint64_t dense_visits_zero;   /* every term exactly 0 (absorber behind all samples): skipped         */
+    uint64_t dense_visits_common; /* every term exactly -2 A_j (absorber in front of all samples): one fma */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

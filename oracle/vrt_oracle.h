@@ -8,14 +8,24 @@
  *
  * Pinning status (see DESIGN.md "Oracle"):
  *   - erf/exp approximations: PINNED against the real reference approx.cpp
- *     compiled in place (oracle/_ref) and against tests/golden/approx_*.npz.
- *   - transmittance / radiance / render / tiling: the reference holds no golden
- *     vectors for these and rt.h cannot be compiled here
- *     (it needs glm, which the image lacks).  They are pinned by (a) the
- *     reference test's own property (analytic transmittance == numeric
- *     integral, tests/transmittance.cpp:24-31) and (b) the reference-produced
- *     images thesis/images/{teapot,cube}.png.  Where neither applies the
- *     function is marked "parity unpinned" below.
+ *     compiled in place (oracle/_ref) and against tests/golden/approx_ref.npz.
+ *   - OBJ loader, camera, tile_gaussians, radiance / transmittance (A&S erf, VCL
+ *     exp), rounding pack with computed alpha, PNG byte order: PINNED against the
+ *     one image in the reference tree that the reference renderer produced,
+ *     thesis/images/teapot.png (fixture tests/golden/thesis/teapot.png).  Its
+ *     command line, found by search (tools/thesis_png_fit.py), is
+ *     `-f test-objects/teapot.obj -w 1024 --focal-length 1.7`; this restatement
+ *     and the SIMD port (vrt_cpu_simd.*) reproduce the PNG within ONE u8 step on
+ *     every sampled channel value (tests/test_reference_golden.py) -- the size
+ *     of the reference's own rcp-estimate noise.
+ *   - NOT pinned by a reference output: the scalar-mode variants (truncating
+ *     pack, opaque alpha, expf/erff: rt.h:227-310), the alternative
+ *     approximations inside a render, transmittance_step / density, and the
+ *     orbit step.  These are held to the reference test's own property (analytic
+ *     transmittance == numeric integral, tests/transmittance.cpp:24-31) and to
+ *     hand-derived known answers (tests/golden/tile_counts.json).  rt.h itself
+ *     cannot be compiled here (it needs glm, which the image lacks), and
+ *     thesis/images/cube.png could not be matched to a command line.
  *
  * Every function cites the reference file:line it follows
  * (paths relative to /root/reference/src).

@@ -35,7 +35,8 @@ class Stats(C.Structure):
                 ("list_entries", C.c_uint64), ("tile_entries", C.c_uint64), ("overflow_blocks", C.c_uint64),
                 ("lane_entries", C.c_uint64), ("lane_max_entries", C.c_uint64), ("shaded_blocks", C.c_uint64), ("dense_blocks", C.c_uint64),
                 ("dense_busy_frac", C.c_double), ("table_blocks", C.c_uint64),
-                ("lane_pairs", C.c_uint64)]
+                ("lane_pairs", C.c_uint64), ("dense_visits_full", C.c_uint64), ("dense_visits_zero", C.c_uint64),
+                ("dense_visits_common", C.c_uint64)]
 
 
 def build(verbose=False):

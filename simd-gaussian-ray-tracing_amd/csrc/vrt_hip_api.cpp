@@ -77,7 +77,7 @@ struct vrt_hip_ctx {
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
-    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq;
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
     int render_waves_per_cu = 13; // persistent one-wave workgroups per CU: what LDS allows (VGPRs: three per SIMD run at a time; the
                                   // 13th starts when the first retires); VRT_HIP_RENDER_WAVES overrides
@@ -335,7 +335,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
     g.cells_x = c->cells_x; g.cells_y = c->cells_y; g.cstride = c->cstride;
     g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.n_cells = c->n_cells;
-    g.dense = c->c_dense.p; g.dense_sorted = c->c_dense_sorted.p; g.scratch = c->c_scratch.p;
+    g.dense = c->c_dense.p; g.dense_sorted = c->c_dense_sorted.p; g.scratch = c->c_scratch.p; g.slot = c->c_slot.p;
     g.n_active = cnt; g.n_dense = cnt + 2;
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
@@ -373,6 +373,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     HIPCHK(c, c->c_count.reserve(c->n_cells)); HIPCHK(c, c->c_active.reserve(c->n_cells));
     HIPCHK(c, c->c_dense.reserve(c->n_cells));
     HIPCHK(c, c->c_dense_sorted.reserve(c->n_cells));
+    HIPCHK(c, c->c_slot.reserve(c->n_cells));
     HIPCHK(c, c->c_scratch.reserve((size_t)c->num_cus * 4 * c->cstride)); // one slot per dense workgroup (<= 4 per CU)
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
     if (c->table_hx > 0.f) HIPCHK(c, c->c_overflow2.reserve((size_t)c->n_cells * 16));
@@ -403,7 +404,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     f.enabled = fuse ? 1 : 0;
     f.tile_map = fuse ? tile_map : nullptr;
     f.C = cell_grid(c);
-    if (fuse && target) { f.O = *target; f.do_clear = 1; }
+    if (fuse && target) { f.O = *target; f.do_clear = target->sparse ? 0 : 1; }
     c->timeline_tiles = 0;
     if (fuse && getenv("VRT_HIP_TIMELINE")) {
         c->timeline_tiles = n_local;
@@ -440,7 +441,9 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         if (!c->work_is_ref) launch_build_tile_lists(a, f, !device_bin, (uint32_t)nt, st);
         else HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1), 0, 8 * sizeof(uint32_t), st));
         HIPCHK(c, hipGetLastError());
-        launch_build_cell_lists(tables(c), work_lists(c), cell_grid(c), a.R, tile_map, c->n_cells, refine ? 1 : 0, st);
+        launch_build_cell_lists(tables(c), work_lists(c), cell_grid(c), a.R, tile_map, c->n_cells, refine ? 1 : 0,
+                                (target && target->sparse) ? target->keys : nullptr, st);
+        if (target && target->sparse) target->cleared = 1; // a sparse shard stores no empty cells: nothing to clear
         // the set the NEXT generation will add to (if it is a fused one) must be clear
         HIPCHK(c, hipMemsetAsync(other_set, 0, 8 * sizeof(uint32_t), st));
     }
@@ -498,9 +501,13 @@ int check_ready(vrt_hip_ctx *c)
     return VRT_HIP_OK;
 }
 
+enum OutMode { OUT_RASTER = 0, OUT_COMPACT = 1, OUT_SPARSE = 2 };
+uint32_t sparse_capacity(vrt_hip_ctx *c); // cells a sparse shard of this context can hold (the same on every rank)
+
 int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *d_image, float4 *d_rad,
-                  hipStream_t st, bool shard_compact)
+                  hipStream_t st, int out_mode)
 {
+    const bool shard_compact = out_mode != OUT_RASTER; // compact and sparse targets hold this rank's tiles only
     int rc = check_ready(c);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -527,12 +534,22 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     RenderTarget o{};
     o.image = d_image; o.radiance = d_rad; o.pack_flags = pack_flags;
     o.stats = c->stats_on ? c->d_stats.p : nullptr;
-    o.compact = shard_compact ? 1 : 0;
+    o.compact = out_mode == OUT_COMPACT ? 1 : 0;
     if (use_shard) {
         if ((rc = rebuild_shard(c))) return rc;
         o.tile_map = c->tile_map.p; o.n_local_tiles = c->n_local;
     } else {
         o.tile_map = nullptr; o.n_local_tiles = geo.tiles_w * geo.tiles_h;
+    }
+    uint32_t sparse_cap = 0;
+    if (out_mode == OUT_SPARSE) {
+        // d_image is a sparse shard buffer: header | keys | pixels of the stored cells (vrt_kernels.h, RenderTarget)
+        sparse_cap = sparse_capacity(c);
+        o.sparse = 1; o.sparse_hdr = d_image; o.keys = d_image + SPARSE_HDR_WORDS;
+        o.image = d_image + sparse_pixel_offset(sparse_cap);
+        o.cleared = 1;
+        c->lists_dirty = true; // the list kernel files the cell keys into THIS buffer
+        o.sparse_cap = sparse_cap;
     }
     if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
     const TileLists t = work_lists(c);
@@ -552,6 +569,8 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
     // persistent grid: 12 one-wave workgroups per CU (three per SIMD at 145 VGPRs), never more than there are blocks
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * c->render_waves_per_cu);
+    if (out_mode == OUT_SPARSE && grid == 0) // a rank without cells launches no render kernel: nobody writes the header
+        HIPCHK(c, hipMemsetAsync(d_image, 0, SPARSE_HDR_WORDS * sizeof(uint32_t), st));
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
         HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1) + 3, 0, 4 * sizeof(uint32_t), st));
     c->lists_fresh = false;
@@ -681,7 +700,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
-    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_overflow2.release(); c->c_counters.release(); c->c_rq.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_overflow2.release(); c->c_counters.release(); c->c_rq.release(); c->c_slot.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
@@ -934,7 +953,7 @@ int vrt_hip_render_device(vrt_hip_ctx *c, const float origin[3], int pack_flags,
                           void *hip_stream)
 {
     if (!c || !origin) return VRT_HIP_ERR_INVALID;
-    return render_common(c, origin, pack_flags, d_image, (float4 *)d_radiance, (hipStream_t)hip_stream, false);
+    return render_common(c, origin, pack_flags, d_image, (float4 *)d_radiance, (hipStream_t)hip_stream, OUT_RASTER);
 }
 
 int vrt_hip_frame_device(vrt_hip_ctx *c, float tw, float th, const float view[16], const float origin[3], int pack_flags,
@@ -943,7 +962,7 @@ int vrt_hip_frame_device(vrt_hip_ctx *c, float tw, float th, const float view[16
     if (!c || !origin || !d_out) return VRT_HIP_ERR_INVALID;
     int rc = vrt_hip_tile_gaussians_device(c, tw, th, view, hip_stream);
     if (rc) return rc;
-    return render_common(c, origin, pack_flags, d_out, nullptr, (hipStream_t)hip_stream, shard != 0);
+    return render_common(c, origin, pack_flags, d_out, nullptr, (hipStream_t)hip_stream, shard ? OUT_COMPACT : OUT_RASTER);
 }
 
 int vrt_hip_frame(vrt_hip_ctx *c, float tw, float th, const float view[16], const float origin[3], int pack_flags,
@@ -986,7 +1005,7 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     // tables / frame prep outside the timed window (list building is part of a frame, like the reference's tiling)
     if ((rc = prep_frame(c, origin, c->stream))) return rc;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    rc = render_common(c, origin, pack_flags, c->d_image.p, radiance_out ? c->d_rad.p : nullptr, c->stream, false);
+    rc = render_common(c, origin, pack_flags, c->d_image.p, radiance_out ? c->d_rad.p : nullptr, c->stream, OUT_RASTER);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -997,6 +1016,7 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
         unsigned long long st[16];
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
         c->last.lane_pairs = st[12];
+        c->last.dense_visits_full = st[13]; c->last.dense_visits_zero = st[14]; c->last.dense_visits_common = st[15];
         c->last.dense_busy_frac = (st[11] && st[9] > st[8]) ? (double)st[10] / ((double)st[11] * (double)(st[9] - st[8])) : 0.0;
         c->last.shaded_blocks = st[5] + st[6];
         c->last.dense_blocks = st[6];
@@ -1116,7 +1136,7 @@ size_t vrt_hip_shard_pixels(const vrt_hip_ctx *cc)
 int vrt_hip_render_shard_device(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *d_shard, void *hip_stream)
 {
     if (!c || !origin || !d_shard) return VRT_HIP_ERR_INVALID;
-    return render_common(c, origin, pack_flags, d_shard, nullptr, (hipStream_t)hip_stream, true);
+    return render_common(c, origin, pack_flags, d_shard, nullptr, (hipStream_t)hip_stream, OUT_COMPACT);
 }
 
 int vrt_hip_assemble_shards_strided_device(vrt_hip_ctx *c, const uint32_t *d_gathered, size_t rank_stride_px,
@@ -1139,6 +1159,60 @@ int vrt_hip_assemble_shards_device(vrt_hip_ctx *c, const uint32_t *d_gathered, u
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     return vrt_hip_assemble_shards_strided_device(c, d_gathered, vrt_hip_shard_pixels(c), d_image, hip_stream);
+}
+
+// ---- sparse shards: only the cells some Gaussian reaches travel (multi-GPU transport) ------------------------------
+namespace {
+uint32_t sparse_capacity(vrt_hip_ctx *c)
+{
+    if (rebuild_shard(c)) return 0;
+    const TileLists t = tile_geometry(c);
+    const uint32_t cx = (t.tile_w + CELL - 1) / CELL, cy = (t.tile_h + CELL - 1) / CELL;
+    return c->n_slots * cx * cy;
+}
+} // namespace
+
+size_t vrt_hip_sparse_shard_words(const vrt_hip_ctx *cc)
+{
+    vrt_hip_ctx *c = const_cast<vrt_hip_ctx *>(cc);
+    if (!c || !c->rays_set) return 0;
+    const uint32_t cap = sparse_capacity(c);
+    return sparse_pixel_offset(cap) + (size_t)cap * CELL * CELL;
+}
+
+int vrt_hip_frame_sparse_device(vrt_hip_ctx *c, float tw, float th, const float view[16], const float origin[3], int pack_flags,
+                                uint32_t *d_sparse, void *hip_stream)
+{
+    if (!c || !origin || !d_sparse) return VRT_HIP_ERR_INVALID;
+    if ((uintptr_t)d_sparse % 16) return fail(c, VRT_HIP_ERR_INVALID, "frame_sparse: the shard buffer must be 16-byte aligned");
+    int rc = vrt_hip_tile_gaussians_device(c, tw, th, view, hip_stream);
+    if (rc) return rc;
+    return render_common(c, origin, pack_flags, d_sparse, nullptr, (hipStream_t)hip_stream, OUT_SPARSE);
+}
+
+int vrt_hip_scatter_sparse_device(vrt_hip_ctx *c, const uint32_t *const *d_shards, int nshards, int pack_flags, uint32_t *d_image,
+                                  void *hip_stream)
+{
+    if (!c || !d_shards || !d_image || nshards < 1 || nshards > MAX_SHARDS) return VRT_HIP_ERR_INVALID;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const TileLists t = tile_geometry(c);
+    if (t.tile_w == 0 || t.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse: tile size is 0 pixels");
+    ShardPtrs sp{};
+    for (int i = 0; i < nshards; ++i) {
+        if (!d_shards[i]) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse: NULL shard");
+        sp.p[i] = d_shards[i];
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint32_t bg = (pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u; // what the kernels write where nothing is lit
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)d_image, (int)bg, (size_t)c->w * c->h, st));
+    const uint32_t cx = (t.tile_w + CELL - 1) / CELL, cy = (t.tile_h + CELL - 1) / CELL;
+    // any rank's shard holds at most ceil(tiles / 1) * cells-per-tile cells; the grid covers the largest possible shard
+    const uint32_t max_cells = t.tiles_w * t.tiles_h * cx * cy;
+    launch_scatter_sparse(sp, nshards, max_cells, d_image, t, cx, cy, c->w, c->h, st);
+    HIPCHK(c, hipGetLastError());
+    return VRT_HIP_OK;
 }
 
 // ---- point queries ------------------------------------------------------------------------------

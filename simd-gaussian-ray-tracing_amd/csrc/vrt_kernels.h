@@ -11,12 +11,18 @@ constexpr int BLOCK_H = 8;
 constexpr int CELL = 32;          // second-level cull region: 32x32 pixels = 4x4 blocks
 constexpr int TCAP = 1024;        // a tile's candidates kept in LDS by the fused list kernel
 constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate cell kernel (one wave per cell)
-constexpr int PCAP = 128;         // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each)
+#ifndef VRT_PCAP
+#define VRT_PCAP 128
+#endif
+#ifndef VRT_PL
+#define VRT_PL 48
+#endif
+constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each)
 #ifndef VRT_DCAP
 #define VRT_DCAP 1024
 #endif
 constexpr int DCAP = VRT_DCAP;        // per-block candidates the dense kernel keeps in LDS (61 KB with the rest; measured: no change below 64 KB, +4 % at 81 KB, +10 % at 104 KB)
-constexpr int PL = 48;            // per-lane list capacity (u8 positions into the block's candidates)
+constexpr int PL = VRT_PL;        // per-lane list capacity (u8 positions into the block's candidates)
 
 // Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
 struct SceneTables {
@@ -48,6 +54,8 @@ struct CellGrid {
     uint32_t *dense;                 // cell ids with long lists: shaded one 16-wave workgroup per block
     uint32_t *scratch;               // dense kernel: cstride words per workgroup (a block's survivors when they outgrow LDS)
     uint32_t *dense_sorted;          // the same, longest list first (order_dense_kernel): the queue order of the dense kernel
+    uint32_t *slot;                  // [cells] position of a non-empty cell in its queue (bit 31: the dense queue): its place in
+                                     // a sparse shard (RenderTarget::sparse) -- written by the list kernels
     uint32_t *n_active, *n_dense;    // device counters, zeroed before the list kernels add to them
     uint32_t *dense_next;            // work counter of the dense kernel (zeroed with the others)
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
@@ -95,9 +103,18 @@ struct RenderTarget {
     uint32_t n_local_tiles;
     int compact;
     int cleared;              // empty cells were already cleared by the list kernel of this frame
+    // Sparse shard (multi-GPU transport, vrt_hip_frame_sparse_device): only the 32x32-px cells some Gaussian reaches
+    // are stored, cell-major: `image` points at the pixel region, pixel (cx, cy) of the cell in slot s at
+    // image[s*1024 + cy*32 + cx]; slot = position in the active queue, or n_active + position in the dense queue.
+    // keys[slot] = tile id * cells per tile + cell in tile; sparse_hdr[0] = number of cells.  Empty cells are neither
+    // stored nor cleared: whoever assembles the frame fills the background.
+    int sparse;
+    uint32_t *keys, *sparse_hdr;
+    uint32_t sparse_cap;      // capacity (cells) of the shard buffer: header word 1, locates the pixel region
     unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
                                // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
                                // [6]=dense blocks [7]=table blocks [8..11]=dense workgroup timeline [12]=sum over rays of (lane list length)^2
+                               // [13..15]=dense kernel: (emitter chunk, absorber) visits evaluated in full / exactly zero / exactly -2A
     unsigned long long *timeline; // nullable diagnostics: 4 wall_clock64 stamps + the hardware id per one-wave work item (5 words)
 };
 
@@ -115,7 +132,7 @@ void launch_order_dense(const CellGrid &c, hipStream_t st);
 void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
 void launch_build_cell_lists(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
-                             const uint32_t *tile_map, uint32_t n_cells, int refine, hipStream_t st);
+                             const uint32_t *tile_map, uint32_t n_cells, int refine, uint32_t *keys, hipStream_t st);
 
 // per-tile list construction: tile binning (rt.cpp:29-69) and/or tile-level cull ("refine")
 struct Mat4 { float m[16]; };
@@ -152,6 +169,13 @@ void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,
                      uint32_t world, uint64_t rank_stride, const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
 void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);
+// frame assembly from sparse shards: image = background, then every stored cell of every shard to its place
+constexpr int MAX_SHARDS = 64;
+struct ShardPtrs { const uint32_t *p[MAX_SHARDS]; };
+void launch_scatter_sparse(const ShardPtrs &shards, int nshards, uint32_t max_cells, uint32_t *image, const TileLists &t,
+                           uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, hipStream_t st);
+constexpr uint32_t SPARSE_HDR_WORDS = 4; // [0] cells stored, [1] capacity (cells), [2] cells per tile, [3] reserved
+__host__ __device__ inline size_t sparse_pixel_offset(uint32_t cap) { return (SPARSE_HDR_WORDS + (size_t)cap + 3) / 4 * 4; }
 
 // point queries
 void launch_transmittance(const SceneTables &s, const float o[3], const float n[3], const float *d_s, size_t ns,

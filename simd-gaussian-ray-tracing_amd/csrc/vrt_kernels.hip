@@ -440,6 +440,9 @@ __device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/
 // by the fused list kernel; when that did not run for this target (unfused lists, re-render) they are cleared here.
 // ---------------------------------------------------------------------------------------------
 struct BlockPos { uint32_t lt, t, pxt, pyt; bool inside; };
+// where lane `lane` of block `bi` of `cell` writes: raster, compact shard [lt][tile_h][tile_w], or sparse shard (cell-major)
+__device__ __forceinline__ uint64_t out_index(const TileLists &T, const CellGrid &C, const RenderTarget &O, uint32_t cell,
+                                              uint32_t bi, uint32_t lane, const struct BlockPos &p, uint64_t pix, uint32_t n_active);
 __device__ __forceinline__ BlockPos block_of(const TileLists &T, const CellGrid &C, const RenderTarget &O, uint32_t cell,
                                              uint32_t bi, uint32_t lane)
 {
@@ -455,8 +458,25 @@ __device__ __forceinline__ BlockPos block_of(const TileLists &T, const CellGrid 
     return p;
 }
 
+// occupancy experiment knob (csrc/Makefile EXTRA=-DVRT_RENDER_WPE=4): cap the registers for N waves per SIMD
+#ifdef VRT_RENDER_WPE
+#define VRT_RENDER_ATTR __attribute__((amdgpu_waves_per_eu(VRT_RENDER_WPE, VRT_RENDER_WPE)))
+#else
+#define VRT_RENDER_ATTR
+#endif
+__device__ __forceinline__ uint64_t out_index(const TileLists &T, const CellGrid &C, const RenderTarget &O, uint32_t cell,
+                                              uint32_t bi, uint32_t lane, const BlockPos &p, uint64_t pix, uint32_t n_active)
+{
+    if (O.sparse) {
+        const uint32_t s = C.slot[cell];
+        const uint32_t slot = (s & 0x7FFFFFFFu) + ((s >> 31) ? n_active : 0u);
+        return (uint64_t)slot * (CELL * CELL) + ((bi >> 2) * BLOCK_H + (lane >> 3)) * CELL + (bi & 3) * BLOCK_W + (lane & 7);
+    }
+    return O.compact ? ((uint64_t)p.lt * T.tile_h + p.pyt) * T.tile_w + p.pxt : pix;
+}
+
 template <int EXP, int ERF, int EC>
-__global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+__global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
 {
     // every row a kept candidate needs later (absorber: A, B; emitter: mu/sigma, albedo, sigma*mag) is fetched in the one
     // round trip of the block cull: the shading loops then run out of LDS only
@@ -470,6 +490,10 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
         __hip_atomic_store(&C.feedback[0], n_dense_cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const uint32_t n_shade = n_active * 16u; // the dense cells belong to the 16-waves-per-block kernel behind this one
+    if (O.sparse_hdr && wave == 0 && lane == 0) { // sparse shard header; the counts are final: the list kernel is done
+        O.sparse_hdr[0] = n_active + n_dense_cells; O.sparse_hdr[1] = O.sparse_cap;
+        O.sparse_hdr[2] = C.cells_x * C.cells_y; O.sparse_hdr[3] = 0;
+    }
 
     // ---- clear the cells nothing can reach (4 B per ray: the only HBM traffic of most of the frame) ----
     const uint32_t zero_px = (O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
@@ -532,7 +556,7 @@ __global__ __launch_bounds__(64) void render_kernel(SceneTables S, TileLists T, 
         const uint32_t pxc = min(p.pxt, T.tile_w - 1), pyc = min(p.pyt, T.tile_h - 1);
         uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
         if (pix >= npix) { valid = false; pix = npix - 1; }
-        const uint64_t out = O.compact ? ((uint64_t)p.lt * T.tile_h + p.pyt) * T.tile_w + p.pxt : pix;
+        const uint64_t out = out_index(T, C, O, cell, bi, lane, p, pix, n_active);
 
         // the cell's candidate list (or, if it overflowed its slot, the tile's)
         uint32_t n_list = C.count[cell];
@@ -677,6 +701,9 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
     const uint32_t *dense_queue = C.dense_is_sorted ? C.dense_sorted : C.dense;
     uint32_t *scratch = C.scratch + (size_t)blockIdx.x * C.cstride;
     const unsigned long long t_start = O.stats ? wall_clock64() : 0ull;
+    // what the saturation tests decide, per (emitter chunk, absorber) visit of this wave (wave-uniform: scalar adds
+    // beside the vector work; written out only when statistics are on)
+    uint32_t n_visit_full = 0, n_visit_zero = 0, n_visit_common = 0;
 
     for (;;) {
         __syncthreads(); // everyone is done with the previous item's LDS
@@ -684,6 +711,10 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
         __syncthreads();
         const uint32_t item = s_item;
         if (item >= n_items) {
+            if (O.stats && lane == 0) {
+                atomicAdd(&O.stats[13], (unsigned long long)n_visit_full); atomicAdd(&O.stats[14], (unsigned long long)n_visit_zero);
+                atomicAdd(&O.stats[15], (unsigned long long)n_visit_common);
+            }
             if (O.stats && tid == 0) { // workgroup timeline: how long the queue kept this workgroup busy
                 const unsigned long long t_end = wall_clock64();
                 atomicMin(&O.stats[8], t_start); atomicMax(&O.stats[9], t_end);
@@ -701,7 +732,10 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
         const uint32_t pxc = min(p.pxt, T.tile_w - 1), pyc = min(p.pyt, T.tile_h - 1);
         uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
         if (pix >= npix) { valid = false; pix = npix - 1; }
-        const uint64_t out = O.compact ? ((uint64_t)p.lt * T.tile_h + p.pyt) * T.tile_w + p.pxt : pix;
+        const uint32_t n_active_cells = *C.n_active;
+        const uint64_t out = out_index(T, C, O, cell, bi, lane, p, pix, n_active_cells);
+        if (O.sparse && item < n_dense16 && bi == 0 && tid == 0) // a dense cell's key (the active cells' are filed by the list kernel)
+            O.keys[n_active_cells + (C.slot[cell] & 0x7FFFFFFFu)] = p.t * (C.cells_x * C.cells_y) + cell % (C.cells_x * C.cells_y);
 
         uint32_t n_list = C.count[cell];
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
@@ -819,10 +853,11 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                     // argument range over the chunk's samples on this ray: [(s_min - mubar_j) r_j, (s_max - mubar_j) r_j]
                     const float hi = __builtin_fmaf(s_max, cb.x, -m), lo = __builtin_fmaf(s_min, cb.x, -m);
                     const bool front = m >= SAT;
-                    if (SKIP && __all(front && hi <= -SAT_M)) continue;
+                    if (SKIP && __all(front && hi <= -SAT_M)) { ++n_visit_zero; continue; }
                     const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
                     const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
-                    if (SKIP && __all(front && lo >= SAT_M)) { common = __builtin_fmaf(A, -2.f, common); continue; }
+                    if (SKIP && __all(front && lo >= SAT_M)) { common = __builtin_fmaf(A, -2.f, common); ++n_visit_common; continue; }
+                    ++n_visit_full;
                     const float E = verf<ERF>(-m);
 #pragma unroll
                     for (int e = 0; e < EC; ++e) {
@@ -930,7 +965,10 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
         const uint32_t pxc = min(p.pxt, T.tile_w - 1), pyc = min(p.pyt, T.tile_h - 1);
         uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
         if (pix >= npix) { valid = false; pix = npix - 1; }
-        const uint64_t out = O.compact ? ((uint64_t)p.lt * T.tile_h + p.pyt) * T.tile_w + p.pxt : pix;
+        const uint32_t n_active_cells = *C.n_active;
+        const uint64_t out = out_index(T, C, O, cell, bi, lane, p, pix, n_active_cells);
+        if (O.sparse && item < n_dense16 && bi == 0 && tid == 0) // a dense cell's key (the active cells' are filed by the list kernel)
+            O.keys[n_active_cells + (C.slot[cell] & 0x7FFFFFFFu)] = p.t * (C.cells_x * C.cells_y) + cell % (C.cells_x * C.cells_y);
 
         uint32_t n_list = C.count[cell];
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
@@ -1418,9 +1456,18 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
         base_a = (uint32_t)__shfl((int)base_a, 0, 64); base_d = (uint32_t)__shfl((int)base_d, 0, 64);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t cell = lt * cpt + lane;
-        if (mine == 1u) C.active[base_a + (uint32_t)__popcll(m_act & below)] = cell;
-        else if (mine == 3u) C.dense[base_d + (uint32_t)__popcll(m_dense & below)] = cell;
-        else if (mine == 0u) s_inact[(uint32_t)__popcll(m_empty & below)] = lane;
+        if (mine == 1u) {
+            const uint32_t pos = base_a + (uint32_t)__popcll(m_act & below);
+            C.active[pos] = cell;
+            if (C.slot) C.slot[cell] = pos;
+            if (F.O.sparse) F.O.keys[pos] = t * cpt + lane;
+        } else if (mine == 3u) {
+            const uint32_t pos = base_d + (uint32_t)__popcll(m_dense & below);
+            C.dense[pos] = cell;
+            if (C.slot) C.slot[cell] = pos | 0x80000000u;
+        } else if (mine == 0u) {
+            s_inact[(uint32_t)__popcll(m_empty & below)] = lane;
+        }
     }
     __syncthreads();
 
@@ -1471,7 +1518,8 @@ void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list
 // which 4096 single-cell atomics would turn into the longest kernel.  Empty cells: count == 0, no queue.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
-                                                                 const uint32_t *tile_map, uint32_t n_cells, int refine)
+                                                                 const uint32_t *tile_map, uint32_t n_cells, int refine,
+                                                                 uint32_t *keys /* sparse shard keys, nullable */)
 {
     __shared__ uint32_t s_flag[16];  // 0 = empty, 1 = active (sparse), 3 = active (dense), 2 = no such cell
     __shared__ uint32_t s_base[3];
@@ -1528,17 +1576,24 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
         uint32_t before = 0;
         const uint32_t mine = s_flag[wave];
         for (uint32_t w = 0; w < wave; ++w) before += s_flag[w] == mine;
-        if (mine == 1u) C.active[s_base[0] + before] = cell;
-        else if (mine == 3u) C.dense[s_base[2] + before] = cell;
+        if (mine == 1u) {
+            C.active[s_base[0] + before] = cell;
+            if (C.slot) C.slot[cell] = s_base[0] + before;
+            if (keys) {
+                const uint32_t cpt = C.cells_x * C.cells_y, lt = cell / cpt;
+                keys[s_base[0] + before] = (tile_map ? tile_map[lt] : lt) * cpt + cell % cpt;
+            }
+        }
+        else if (mine == 3u) { C.dense[s_base[2] + before] = cell; if (C.slot) C.slot[cell] = (s_base[2] + before) | 0x80000000u; }
     }
 }
 
 void launch_build_cell_lists(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
-                             const uint32_t *tile_map, uint32_t n_cells, int refine, hipStream_t st)
+                             const uint32_t *tile_map, uint32_t n_cells, int refine, uint32_t *keys, hipStream_t st)
 {
     if (!n_cells) return;
     hipLaunchKernelGGL(build_cell_lists_kernel, dim3((n_cells + 15) / 16), dim3(1024), 0, st, s, t, c, r, tile_map,
-                       n_cells, refine);
+                       n_cells, refine, keys);
 }
 
 // scatter rank-major shard buffers [rank](stride rank_stride)[slot][tile_h][tile_w] into the raster image (rt.h:388-399)
@@ -1567,6 +1622,42 @@ void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *
     const uint32_t gx = min((per_tile + 255u) / 256u, 64u);
     hipLaunchKernelGGL(assemble_kernel, dim3(gx ? gx : 1, n_slots), dim3(256), 0, st, gathered, image, tile_of_slot, t,
                        width, height, slots_per_rank, rank_stride);
+}
+
+// Frame assembly from sparse shards (multi-GPU): one workgroup per (shard, slot).  The shards may live in another
+// GPU's memory (peer access over xGMI): they are read once, 16 B per lane, and only the stored cells travel.
+__global__ __launch_bounds__(256) void scatter_sparse_kernel(ShardPtrs shards, uint32_t max_cells, uint32_t *image, TileLists T,
+                                                             uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height)
+{
+    const uint32_t *sh = shards.p[blockIdx.y];
+    const uint32_t slot = blockIdx.x, n = sh[0], cap = sh[1];
+    if (slot >= n || slot >= max_cells) return;
+    const uint32_t cpt = cells_x * cells_y;
+    const uint32_t key = sh[SPARSE_HDR_WORDS + slot];
+    const uint32_t t = key / cpt, ci = key % cpt;
+    if (t >= T.tiles_w * T.tiles_h) return;
+    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+    const uint4 *src = reinterpret_cast<const uint4 *>(sh + sparse_pixel_offset(cap) + (size_t)slot * (CELL * CELL));
+    const uint64_t npix = (uint64_t)width * height;
+    for (uint32_t q = threadIdx.x; q < CELL * CELL / 4; q += blockDim.x) { // one 4-pixel quad per lane and pass
+        const uint4 v = src[q];
+        const uint32_t cx = (q % (CELL / 4)) * 4, cy = q / (CELL / 4);
+        const uint32_t pxt = (ci % cells_x) * CELL + cx, pyt = (ci / cells_x) * CELL + cy;
+        if (pyt >= T.tile_h) continue;
+        const uint64_t pix = (uint64_t)(tx * T.tile_w + pxt) + (uint64_t)T.stride * (ty * T.tile_h + pyt);
+        const uint32_t px[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (pxt + k < T.tile_w && pix + k < npix) image[pix + k] = px[k];
+    }
+}
+
+void launch_scatter_sparse(const ShardPtrs &shards, int nshards, uint32_t max_cells, uint32_t *image, const TileLists &t,
+                           uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, hipStream_t st)
+{
+    if (nshards <= 0 || !max_cells) return;
+    hipLaunchKernelGGL(scatter_sparse_kernel, dim3(max_cells, (uint32_t)nshards), dim3(256), 0, st, shards, max_cells, image, t,
+                       cells_x, cells_y, width, height);
 }
 
 // ---------------------------------------------------------------------------------------------

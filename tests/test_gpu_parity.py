@@ -103,6 +103,19 @@ def test_tile_binning_matches_reference_algorithm(pkg, oracle, renderer):
                                           tiles["indices"][tiles["offsets"][t]:tiles["offsets"][t + 1]])
 
 
+def test_device_binning_matches_hand_derived_tile_counts(pkg, oracle, renderer):
+    """Device tile_gaussians against tests/golden/tile_counts.json: the per-axis counts SURVEY.md 8(c) derived by hand
+    from rt.cpp:58-59 for the three grid configs -- a known answer that is not this repository's output."""
+    import json
+    gold = json.load(open(os.path.join(GOLDEN, "tile_counts.json")))
+    cam, _ = oracle.cli_camera(64, 64)
+    for name, sc in gold["scenes"].items():
+        renderer.set_gaussians(oracle.grid_scene(sc["grid"]))
+        renderer.tile_gaussians(gold["tw"], gold["tw"], oracle.camera_view(cam))
+        pa = np.array(sc["per_axis"])
+        np.testing.assert_array_equal(renderer.tile_counts(), np.outer(pa, pa), err_msg=name)
+
+
 def test_host_tiles_equal_device_tiles(pkg, oracle, renderer):
     """vrt_hip_set_tiles (caller-made tiles_t) and vrt_hip_tile_gaussians give the same image."""
     w = h = 128

@@ -23,7 +23,7 @@ def run(name, g, w, eps=1e-9, reps=5):
         r.render_device(cam.position, pkg.PACK_ROUND | pkg.ALPHA_COMPUTED, img_t.data_ptr(), 0, s)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     rays_l = st["lane_entries"]
-    print(f"{name:10s} w={w} eps={eps:g} frame {dt*1e3:8.3f} ms  {w*w/dt/1e6:9.1f} Mray/s | shaded blocks {sb} of {st['blocks']}, block list {st['list_entries']/sb:.1f}, cell list {st['tile_entries']/sb:.1f}, ray list {rays_l/(sb*64):.1f}, longest {st['lane_max_entries']/sb:.1f}, slow-path {st['overflow_blocks']}, dense blocks {st['dense_blocks']} busy {st['dense_busy_frac']:.2f}")
+    print(f"{name:10s} w={w} eps={eps:g} frame {dt*1e3:8.3f} ms  {w*w/dt/1e6:9.1f} Mray/s | shaded blocks {sb} of {st['blocks']}, block list {st['list_entries']/sb:.1f}, cell list {st['tile_entries']/sb:.1f}, ray list {rays_l/(sb*64):.1f}, longest {st['lane_max_entries']/sb:.1f}, dense blocks {st['dense_blocks']} (>1024 survivors: {st['overflow_blocks']}) busy {st['dense_busy_frac']:.2f}, dense visits full/zero/-2A {st['dense_visits_full']:.3e}/{st['dense_visits_zero']:.3e}/{st['dense_visits_common']:.3e}")
 teapot = scene.read_obj(os.path.join(GOLDEN, "test-objects", "teapot.obj"))
 monkey = scene.read_obj(os.path.join(GOLDEN, "test-objects", "monkey.obj"))
 cube = scene.read_obj(os.path.join(GOLDEN, "test-objects", "cube.obj"))

@@ -24,7 +24,12 @@ __global__ void fma_loop(float *out, unsigned long long *stamps, float a, float 
                      "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    // the SIMD arbiter favours its oldest wave: wave 0 alone would read its own, shortest, run time -- take the
+    // workgroup's span (earliest start to latest end over its waves)
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&stamps[4 * blockIdx.x], c0); atomicMax(&stamps[4 * blockIdx.x + 1], c1);
+        atomicMin(&stamps[4 * blockIdx.x + 2], r0); atomicMax(&stamps[4 * blockIdx.x + 3], r1);
+    }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
 
@@ -35,12 +40,14 @@ int main()
     float *out;
     unsigned long long *stamps;
     hipMalloc(&out, sizeof(float) * 1024 * cus);
-    hipMalloc(&stamps, sizeof(unsigned long long) * 2 * cus);
+    hipMalloc(&stamps, sizeof(unsigned long long) * 4 * cus);
+    std::vector<unsigned long long> init(4 * cus);
+    for (int i = 0; i < cus; ++i) { init[4 * i] = init[4 * i + 2] = ~0ull; init[4 * i + 1] = init[4 * i + 3] = 0; }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("{\"what\": \"v_fma_f32 x8 independent, %d iterations, one workgroup per CU (tools/ubench/valu_clock.hip)\", \"cus\": %d, \"runs\": [", N_IT, cus);
     bool first = true;
-    for (int wps : {1, 2, 3, 4, 8}) {
+    for (int wps : {1, 2, 3, 4}) {
         const int threads = wps * 4 * 64;
         // keep the chip busy first: the clock under load is what a frame loop sees
         for (int r = 0; r < (wps == 1 ? 600 : 300) / wps; ++r) hipLaunchKernelGGL(fma_loop, dim3(cus), dim3(threads), 0, 0, out, stamps, 0.999f, 0.5f);
@@ -52,12 +59,17 @@ int main()
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
-        std::vector<unsigned long long> h(2 * cus);
+        // one more launch, stamped from clean min/max slots
+        hipMemcpy(stamps, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(fma_loop, dim3(cus), dim3(threads), 0, 0, out, stamps, 0.999f, 0.5f);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(4 * cus);
         hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         std::vector<double> cyc(cus), clk(cus);
         for (int i = 0; i < cus; ++i) {
-            cyc[i] = (double)h[2 * i] / ((double)N_IT * 8 * wps); // shader cycles per wave-instruction per SIMD
-            clk[i] = (double)h[2 * i] / (double)h[2 * i + 1] * 0.1; // GHz (s_memrealtime ticks at 100 MHz)
+            const double dc = (double)(h[4 * i + 1] - h[4 * i]), dr = (double)(h[4 * i + 3] - h[4 * i + 2]);
+            cyc[i] = dc / ((double)N_IT * 8 * wps); // shader cycles per wave-instruction per SIMD
+            clk[i] = dc / dr * 0.1;                  // GHz (s_memrealtime ticks at 100 MHz)
         }
         std::nth_element(cyc.begin(), cyc.begin() + cus / 2, cyc.end());
         std::nth_element(clk.begin(), clk.begin() + cus / 2, clk.end());
