@@ -228,22 +228,29 @@ def main():
     frame = frames[0]
     img_ptrs = [im.data_ptr() for im in images]
     img_ptr = img_ptrs[0]
-    # N > 1: sharding.FrameGatherer -- every rank renders its tile shard of F consecutive frames into one buffer, ONE
-    # gather per F frames moves them to rank 0 (double-buffered against the next batch's rendering), rank 0 assembles
-    # every gathered frame into raster order.  The same class runs under gloo in tests/test_dist_gloo.py.
+    # N > 1: sharding.SparseFrameGatherer -- every rank renders its tile shard of F consecutive frames as SPARSE shards
+    # (only the 32x32-px cells a Gaussian reaches are stored: ~0.8 MB of this 16 MB frame), ONE gather per F frames moves
+    # the used prefixes to rank 0 (double-buffered against the next batch's rendering), rank 0 assembles every gathered
+    # frame: background + stored cells (vrt_hip_scatter_sparse_device).  The same class runs under gloo in
+    # tests/test_dist_gloo.py.
     F = max(1, min(args.gather_frames, max(args.steps, 1)))
     if not solo:
-        from sgrt_amd.sharding import FrameGatherer
-        npx = r.shard_pixels()
-        fg = FrameGatherer(dist, rank, world, npx, F, "cuda", stage=backend != "nccl")
+        from sgrt_amd.sharding import SparseFrameGatherer, sparse_pixel_offset
+        words = r.sparse_shard_words()
+        cap = None
+        for c_ in range(1, words):          # capacity from the buffer size: words = offset(cap) + 1024 cap
+            if sparse_pixel_offset(c_) + 1024 * c_ == words:
+                cap = c_
+                break
+        fg = SparseFrameGatherer(dist, rank, world, words, cap, F, "cuda", stage=backend != "nccl")
+        sparse_frame = r.frame_sparse_call(tw, th, view, origin, pack)
         shard_ptr = [t_.data_ptr() for t_ in fg.shard]
-        gath_ptr = [t_.data_ptr() if t_ is not None else 0 for t_ in fg.gathered]
 
         def render_shard(b, f):
-            frame(shard_ptr[b] + 4 * f * npx, sp)
+            sparse_frame(shard_ptr[b] + 4 * f * words, sp)
 
         def assemble(b, f):
-            r.assemble_shards_device(gath_ptr[b] + 4 * f * npx, img_ptr, sp, rank_stride_px=F * npx)
+            r.scatter_sparse_device([t_.data_ptr() for t_ in fg.gathered_shards(b, f)], pack, img_ptr, sp)
 
     def run(nsteps, in_flight=nctx):
         if solo:
@@ -388,7 +395,9 @@ def main():
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
                        "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
                        "parallelism": (f"whole frames on each of {world} ranks, no collective" if (solo and world > 1) else
-                                       f"tile-shard x{world}" + (f" + RCCL gather to rank 0 every {F} frames" if world > 1 else "")),
+                                       f"tile-shard x{world}" + (f" + RCCL gather of sparse shards to rank 0 every {F} frames" if world > 1 else "")),
+                       "shard_transport": (None if solo else {"format": "sparse: 32x32-px cells that hold something", "bytes_per_frame":
+                                           fg.bytes_moved / max(1, fg.frames_moved), "compact_shards_would_be": (world - 1) * w * h * 4 // world}),
                        "frames_in_flight": nctx,
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -19,6 +19,12 @@
  *     renders from one thread, main.cpp:257-296).
  *   - *_device variants take DEVICE pointers and a hipStream_t (as void*) and are
  *     asynchronous; the others take HOST pointers and return after completion.
+ *   - Streams: frames enqueued through a *_device call run on the caller's stream and read
+ *     the context's tables, lists and plane arrays.  Every call that rewrites one of those
+ *     (set_gaussians*, set_plane, set_tiles, tile_gaussians with another tile size, a frame
+ *     on another stream) first waits for the frames in flight, so no synchronisation by the
+ *     caller is needed before changing state.  A stream passed to a *_device call has to
+ *     stay valid until the context's next state change, vrt_hip_sync() or destroy.
  *
  * All paths are relative to /root/reference/src.
  */
@@ -108,6 +114,9 @@ int vrt_hip_set_camera(vrt_hip_ctx *ctx, uint32_t w, uint32_t h, const float pos
  * points -- which the reference's |oc|^2 - mubar^2 can amplify to 1e-4 for small sigma.) */
 int vrt_hip_set_camera_view(vrt_hip_ctx *ctx, uint32_t width, uint32_t height, const float view[16]);
 
+/* width * height of the current ray set-up (0 before any set_plane / set_camera*). */
+size_t vrt_hip_image_pixels(const vrt_hip_ctx *ctx);
+
 /* -------- host camera: replaces camera_t (camera.h:20-44, camera.cpp:7-71) -------------------------------- */
 /* Pure host code (no GPU needed, no context): the reference's yaw/pitch camera evaluated in glm's order of operations
  * (lookAtRH -> translate -> inverse -> mat4*vec4, unfused), so that view matrices and projection-plane points are the
@@ -175,6 +184,43 @@ int vrt_hip_assemble_shards_device(vrt_hip_ctx *ctx, const uint32_t *d_gathered,
  * assemble starts at d_gathered + r * rank_stride_px (pass d_gathered already offset to the frame). */
 int vrt_hip_assemble_shards_strided_device(vrt_hip_ctx *ctx, const uint32_t *d_gathered, size_t rank_stride_px,
                                            uint32_t *d_image, void *hip_stream);
+
+/* Sparse shards: the transport format for small frames.  Most of a frame is background (95 % of `-g 64 -w 2048`), so a
+ * rank ships only the 32x32-pixel cells that some Gaussian reaches.  Buffer layout, u32 words (16-byte aligned):
+ *   [0] cells stored   [1] capacity C (cells)   [2] cells per tile   [3] 0
+ *   [4 .. 4+C)         key of the cell in each slot: tile id * cells per tile + cell in tile (row-major 32-px cells)
+ *   [P ..)             32*32 pixels per stored cell, P = 4 + C rounded up to a multiple of 4
+ * C is the same on every rank of a job, so a fixed-size prefix [0, P + 1024 * max cells) can travel through a gather.
+ * frame_sparse == vrt_hip_frame_device into such a buffer; scatter_sparse builds the raster frame on the assembling
+ * rank: background everywhere, then every stored cell of every shard.  The shard pointers must be readable from this
+ * context's device: own memory, a gathered copy, or another GPU's memory with peer access enabled (xGMI). */
+/* words of a shard buffer for the CURRENT tile grid and shard (call after tile_gaussians / set_tiles / set_shard) */
+size_t vrt_hip_sparse_shard_words(const vrt_hip_ctx *ctx);
+int vrt_hip_frame_sparse_device(vrt_hip_ctx *ctx, float tw, float th, const float view[16], const float origin[3],
+                                int pack_flags, uint32_t *d_sparse, void *hip_stream);
+int vrt_hip_scatter_sparse_device(vrt_hip_ctx *ctx, const uint32_t *const *d_shards, int nshards, int pack_flags,
+                                  uint32_t *d_image, void *hip_stream);
+
+/* -------- several GPUs from one process: replaces the thread pool over tiles (rt.h:355-399) one level up -------------
+ * A group holds one context per entry of `devices` (a device may be listed more than once: each entry is a member
+ * with its own stream -- how the protocol is tested on a one-GPU box).  Scene, options and rays are set per member
+ * through vrt_hip_group_ctx(); vrt_hip_group_frame renders ONE frame tile-sharded over the members: member i renders
+ * the tiles of shard (i, n) as a sparse shard on its own device and stream, member 0 waits for all of them (events),
+ * reads the shards -- directly over xGMI where peer access exists, through a copy otherwise -- and assembles the
+ * raster frame (the copy loop of rt.h:388-399).  Animations that do not need every frame in one place should deal
+ * whole frames to the members instead (vrt_hip_frame on vrt_hip_group_ctx(g, k % n)): no exchange at all. */
+typedef struct vrt_hip_group vrt_hip_group;
+int vrt_hip_group_create(const int *devices, int n, vrt_hip_group **out);
+void vrt_hip_group_destroy(vrt_hip_group *g);
+int vrt_hip_group_size(const vrt_hip_group *g);
+vrt_hip_ctx *vrt_hip_group_ctx(vrt_hip_group *g, int member);
+const char *vrt_hip_group_last_error(const vrt_hip_group *g);
+/* image_out (host, w*h u32) may be NULL; wait != 0 or image_out != NULL: returns when the frame is complete. */
+int vrt_hip_group_frame(vrt_hip_group *g, float tw, float th, const float view[16], const float origin[3], int pack_flags,
+                        uint32_t *image_out, int wait);
+/* The assembled frame on member 0's device (valid until the next group_frame), for callers that keep it on the GPU. */
+const uint32_t *vrt_hip_group_image_device(const vrt_hip_group *g);
+int vrt_hip_group_sync(vrt_hip_group *g);
 
 /* -------- point queries: replace transmittance / radiance (rt.h:32-54, 146-223) ----------- */
 /* T_out[k] = transmittance<Exp,Erf>(o, n, s[k], all Gaussians of the scene), rt.h:32-54. */

@@ -76,6 +76,18 @@ SYMBOLS = {
     "vrt_hip_sync": (C.c_int, [_vp]),
     "vrt_hip_assemble_shards_device": (C.c_int, [_vp, _vp, _vp, _vp]),
     "vrt_hip_assemble_shards_strided_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "vrt_hip_image_pixels": (C.c_size_t, [_vp]),
+    "vrt_hip_sparse_shard_words": (C.c_size_t, [_vp]),
+    "vrt_hip_frame_sparse_device": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, _vp]),
+    "vrt_hip_scatter_sparse_device": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int, _vp, _vp]),
+    "vrt_hip_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "vrt_hip_group_destroy": (None, [_vp]),
+    "vrt_hip_group_size": (C.c_int, [_vp]),
+    "vrt_hip_group_ctx": (_vp, [_vp, C.c_int]),
+    "vrt_hip_group_last_error": (C.c_char_p, [_vp]),
+    "vrt_hip_group_frame": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _u32p, C.c_int]),
+    "vrt_hip_group_image_device": (_vp, [_vp]),
+    "vrt_hip_group_sync": (C.c_int, [_vp]),
     "vrt_hip_transmittance": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, _f32p]),
     "vrt_hip_transmittance_rays": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p, _f32p]),
     "vrt_hip_radiance": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p]),
@@ -129,19 +141,23 @@ def _f3(v):
 class Renderer:
     """One context = one GPU.  Mirrors the reference call set (main.cpp:257-296)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _handle=None):
         self._L = lib()
-        h = _vp()
-        rc = self._L.vrt_hip_create(device, C.byref(h))
-        if rc != 0:
-            raise VrtHipError(f"vrt_hip_create({device}) failed ({rc}): {self._L.vrt_hip_last_error(None).decode()}")
-        self._h = h
+        self._owned = _handle is None
+        if _handle is None:
+            h = _vp()
+            rc = self._L.vrt_hip_create(device, C.byref(h))
+            if rc != 0:
+                raise VrtHipError(f"vrt_hip_create({device}) failed ({rc}): {self._L.vrt_hip_last_error(None).decode()}")
+            _handle = h
+        self._h = _handle
         self.n = 0
         self.w = self.h = 0
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.vrt_hip_destroy(self._h)
+            if self._owned:
+                self._L.vrt_hip_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -267,6 +283,29 @@ class Renderer:
         self._chk(self._L.vrt_hip_render_shard_device(self._h, _fp(_f3(origin)), pack, d_shard, stream or None),
                   "render_shard_device")
 
+    # ---- sparse shards (only the non-empty 32x32 cells travel) ----
+    def sparse_shard_words(self):
+        return self._L.vrt_hip_sparse_shard_words(self._h)
+
+    def frame_sparse_call(self, tw, th, view, origin, pack):
+        """Pre-marshalled vrt_hip_frame_sparse_device: returns f(d_sparse, stream)."""
+        v = np.ascontiguousarray(view, np.float32).ravel().copy()
+        o = _f3(origin).copy()
+        fn, h, vp, op = self._L.vrt_hip_frame_sparse_device, self._h, _fp(v), _fp(o)
+        tw, th, pack = float(tw), float(th), int(pack)
+
+        def call(d_sparse, stream=0, _keep=(v, o)):
+            rc = fn(h, tw, th, vp, op, pack, d_sparse, stream or None)
+            if rc != 0:
+                self._chk(rc, "frame_sparse_device")
+        return call
+
+    def scatter_sparse_device(self, shard_ptrs, pack, d_image, stream=0):
+        """Background + every stored cell of every shard (device pointers readable from this context's GPU)."""
+        arr = (_vp * len(shard_ptrs))(*[int(p) for p in shard_ptrs])
+        self._chk(self._L.vrt_hip_scatter_sparse_device(self._h, arr, len(shard_ptrs), int(pack), d_image, stream or None),
+                  "scatter_sparse_device")
+
     def assemble_shards_device(self, d_gathered, d_image, stream=0, rank_stride_px=None):
         """Scatter a rank-major gather result into raster order; rank_stride_px > shard_pixels() when the gather
         carried several frames per rank (d_gathered then points at the frame's slice of rank 0)."""
@@ -348,3 +387,46 @@ class Renderer:
         s = Stats()
         self._chk(self._L.vrt_hip_get_stats(self._h, C.byref(s)), "get_stats")
         return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+
+class Group:
+    """Several GPUs from one process (vrt_hip_group_*): one member context per entry of `devices`; a device listed twice
+    gives two members on it (protocol tests on a one-GPU box)."""
+
+    def __init__(self, devices):
+        self._L = lib()
+        d = (C.c_int * len(devices))(*devices)
+        h = _vp()
+        rc = self._L.vrt_hip_group_create(d, len(devices), C.byref(h))
+        if rc != 0:
+            raise VrtHipError(f"vrt_hip_group_create failed ({rc}): {self._L.vrt_hip_group_last_error(None).decode()}")
+        self._g = h
+        self.members = [Renderer(_handle=_vp(self._L.vrt_hip_group_ctx(h, i))) for i in range(len(devices))]
+
+    def frame(self, tw, th, view, origin, pack, want_image=True, wait=True):
+        w, h = self.members[0].w, self.members[0].h
+        img = np.zeros(w * h, np.uint32) if want_image else None
+        v = np.ascontiguousarray(view, np.float32).ravel()
+        rc = self._L.vrt_hip_group_frame(self._g, float(tw), float(th), _fp(v), _fp(_f3(origin)), int(pack),
+                                         img.ctypes.data_as(_u32p) if want_image else None, int(wait))
+        if rc != 0:
+            raise VrtHipError(f"group_frame failed ({rc}): {self._L.vrt_hip_group_last_error(self._g).decode()}")
+        return img.reshape(h, w) if want_image else None
+
+    def sync(self):
+        rc = self._L.vrt_hip_group_sync(self._g)
+        if rc != 0:
+            raise VrtHipError(f"group_sync failed ({rc}): {self._L.vrt_hip_group_last_error(self._g).decode()}")
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for m in self.members:
+                m.close()
+            self._L.vrt_hip_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

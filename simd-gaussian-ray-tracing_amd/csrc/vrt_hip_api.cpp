@@ -79,6 +79,7 @@ struct vrt_hip_ctx {
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
+    int render_nw = 1;            // waves per block in the block kernel (VRT_HIP_RENDER_NW = 1 | 2): see render_kernel
     int render_waves_per_cu = 13; // persistent one-wave workgroups per CU: what LDS allows (VGPRs: three per SIMD run at a time; the
                                   // 13th starts when the first retires); VRT_HIP_RENDER_WAVES overrides
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
@@ -568,7 +569,8 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     c->last.blocks = (uint64_t)o.n_local_tiles * bx * by;
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
     // persistent grid: 12 one-wave workgroups per CU (three per SIMD at 145 VGPRs), never more than there are blocks
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * c->render_waves_per_cu);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u,
+                                                       (uint64_t)c->num_cus * std::max(1, c->render_waves_per_cu / c->render_nw));
     if (out_mode == OUT_SPARSE && grid == 0) // a rank without cells launches no render kernel: nobody writes the header
         HIPCHK(c, hipMemsetAsync(d_image, 0, SPARSE_HDR_WORDS * sizeof(uint32_t), st));
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
@@ -593,7 +595,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     cg.rq = c->c_rq.p + (c->rq_gen & 1) * RQ_N * RQ_STRIDE;
     cg.rq_next = c->c_rq.p + ((c->rq_gen + 1) & 1) * RQ_N * RQ_STRIDE;
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
-    launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
+    launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->render_nw, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
     // dense queue: 16-wave workgroups pull blocks until the queue is empty (they exit at once if it is)
     if (expect_dense) launch_order_dense(cg, st);
@@ -676,6 +678,10 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     if (const char *e = getenv("VRT_HIP_RENDER_WAVES")) { // one-wave kernel: persistent waves per CU (tuning knob)
         const int v = atoi(e);
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
+    }
+    if (const char *e = getenv("VRT_HIP_RENDER_NW")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2) c->render_nw = v;
     }
     if (const char *e = getenv("VRT_HIP_DENSE_WAVES")) {
         const int v = atoi(e);
@@ -949,6 +955,8 @@ int vrt_hip_set_camera_view(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float 
     return VRT_HIP_OK;
 }
 
+size_t vrt_hip_image_pixels(const vrt_hip_ctx *c) { return (c && c->rays_set) ? (size_t)c->w * c->h : 0; }
+
 int vrt_hip_render_device(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_t *d_image, float *d_radiance,
                           void *hip_stream)
 {
@@ -1206,10 +1214,15 @@ int vrt_hip_scatter_sparse_device(vrt_hip_ctx *c, const uint32_t *const *d_shard
     }
     hipStream_t st = (hipStream_t)hip_stream;
     const uint32_t bg = (pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u; // what the kernels write where nothing is lit
-    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)d_image, (int)bg, (size_t)c->w * c->h, st));
+    // the tiles cover the linear pixel range [0, stride * tile_h * tiles_h) (rt.h:364-365: pix = x + stride * y with the
+    // truncated tile size); what lies beyond is written by nobody in a single-GPU frame either and reads 0
+    const size_t npix = (size_t)c->w * c->h;
+    const size_t covered = std::min(npix, (size_t)t.stride * t.tile_h * t.tiles_h);
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)d_image, (int)bg, covered, st));
+    if (covered < npix) HIPCHK(c, hipMemsetAsync(d_image + covered, 0, (npix - covered) * sizeof(uint32_t), st));
     const uint32_t cx = (t.tile_w + CELL - 1) / CELL, cy = (t.tile_h + CELL - 1) / CELL;
-    // any rank's shard holds at most ceil(tiles / 1) * cells-per-tile cells; the grid covers the largest possible shard
-    const uint32_t max_cells = t.tiles_w * t.tiles_h * cx * cy;
+    // one workgroup per (shard, slot) up to the shard capacity -- the same on every rank of this context's job
+    const uint32_t max_cells = sparse_capacity(c);
     launch_scatter_sparse(sp, nshards, max_cells, d_image, t, cx, cy, c->w, c->h, st);
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;

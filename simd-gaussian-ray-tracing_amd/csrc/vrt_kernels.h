@@ -124,7 +124,7 @@ void launch_build_static(uint32_t n, const float *mu_x, const float *mu_y, const
                          float cull_eps, float exp_floor_x, float4 *mu_sig, float4 *gB, float4 *gC, float4 *gD,
                          hipStream_t st);
 void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r, const RenderTarget &o,
-                   uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
+                   uint32_t grid /* workgroups */, int nw /* waves per block: 1 or 2 */, int exp_kind, int erf_kind, hipStream_t st);
 void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int dw /* waves per block: 4, 8 or 16 */, int exp_kind,
                          int erf_kind, hipStream_t st);

@@ -475,22 +475,44 @@ __device__ __forceinline__ uint64_t out_index(const TileLists &T, const CellGrid
     return O.compact ? ((uint64_t)p.lt * T.tile_h + p.pyt) * T.tile_w + p.pxt : pix;
 }
 
-template <int EXP, int ERF, int EC>
-__global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+// exactly `size` emitters (list positions i0 .. i0+size-1 of every lane), size 0..4
+template <int EXP, int ERF>
+__device__ __forceinline__ void shade_range(const float4 *s_A, const float4 *s_B, const float4 *s_M, const float4 *s_C,
+                                            const float *s_q, const uint8_t *s_lane, uint32_t nl, uint32_t nmax, uint32_t lane,
+                                            const LaneRay &ray, uint32_t i0, uint32_t size, float &Lr, float &Lg, float &Lb, float &La)
+{
+    Lr = Lg = Lb = La = 0.f;
+    if (size == 4) shade_chunk<EXP, ERF, 4>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+    else if (size == 3) shade_chunk<EXP, ERF, 3>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+    else if (size == 2) shade_chunk<EXP, ERF, 2>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+    else if (size == 1) shade_chunk<EXP, ERF, 1>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+}
+
+// NW = waves per block.  NW = 1: one wavefront shades a block on its own.  NW = 2: the two waves of a workgroup hold the
+// same 64 rays, share ONE block cull and ONE set of per-ray lists through LDS and take half of the emitters each; their
+// partial radiances are added in wave order.  A frame of `-g 64 -w 2048` is ~2500 equally heavy blocks for 1024 SIMDs,
+// three resident waves each: with whole blocks as the unit half of the SIMDs carry three heavy blocks and the rest two
+// (27 us against a balanced 21 us, VRT_HIP_TIMELINE); with half blocks pulled from the work queues the unit is half
+// as long and the per-SIMD sums even out.
+template <int EXP, int ERF, int EC, int NW>
+__global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
 {
     // every row a kept candidate needs later (absorber: A, B; emitter: mu/sigma, albedo, sigma*mag) is fetched in the one
     // round trip of the block cull: the shading loops then run out of LDS only
     __shared__ float4 s_A[PCAP], s_B[PCAP], s_M[PCAP], s_C[PCAP];
     __shared__ float s_q[PCAP];
     __shared__ uint8_t s_lane[PL * 64];
-    const uint32_t lane = threadIdx.x, wave = blockIdx.x, G = gridDim.x;
+    __shared__ float4 s_L[NW > 1 ? 64 : 1];
+    __shared__ uint32_t s_cnt[2], s_item;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wave = blockIdx.x, G = gridDim.x;
+    const bool first = threadIdx.x == 0;
     const uint64_t npix = (uint64_t)R.width * R.height;
     const uint32_t n_active = *C.n_active, n_dense_cells = *C.n_dense;
-    if (C.feedback && wave == 0 && lane == 0) {
+    if (C.feedback && wave == 0 && first) {
         __hip_atomic_store(&C.feedback[0], n_dense_cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const uint32_t n_shade = n_active * 16u; // the dense cells belong to the 16-waves-per-block kernel behind this one
-    if (O.sparse_hdr && wave == 0 && lane == 0) { // sparse shard header; the counts are final: the list kernel is done
+    if (O.sparse_hdr && wave == 0 && first) { // sparse shard header; the counts are final: the list kernel is done
         O.sparse_hdr[0] = n_active + n_dense_cells; O.sparse_hdr[1] = O.sparse_cap;
         O.sparse_hdr[2] = C.cells_x * C.cells_y; O.sparse_hdr[3] = 0;
     }
@@ -498,7 +520,7 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
     // ---- clear the cells nothing can reach (4 B per ray: the only HBM traffic of most of the frame) ----
     const uint32_t zero_px = (O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
     // (only when the list kernel of this frame did not do it: unfused lists, or a re-render from unchanged lists)
-    for (uint32_t cell = wave; cell < C.n_cells && !O.cleared; cell += G) { // one whole cell per item: 16 x (2 rows of 32 px)
+    for (uint32_t cell = wave; cell < C.n_cells && !O.cleared && wv == 0; cell += G) { // one whole cell per item: 16 x (2 rows of 32 px)
         if (C.count[cell] != 0u) continue;
         const uint32_t cpt = C.cells_x * C.cells_y;
         const uint32_t lt = cell / cpt, ci = cell % cpt;
@@ -518,21 +540,28 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
     }
 
     // ---- shade ----
-    if (wave == 0 && lane < RQ_N) C.rq_next[lane * RQ_STRIDE] = 0;
+    if (wave == 0 && threadIdx.x < RQ_N) C.rq_next[threadIdx.x * RQ_STRIDE] = 0;
     const uint32_t n_dyn = n_shade > G ? n_shade - G : 0u;
     uint32_t rq_tries = 0;
     // next block: blocks cost between ~1 and ~30 units (the pair loops are quadratic in the per-ray list length), so
-    // after its static first block a wave pulls more from the queues, its own first, until all are empty
+    // after its static first block a workgroup pulls more from the queues, its own first, until all are empty
     auto next_item = [&]() -> uint32_t {
         while (rq_tries < RQ_N) {
             const uint32_t q = (wave + rq_tries) % RQ_N;
             const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
             uint32_t m = 0xFFFFFFFFu;
-            if (lane == 0 && per) {
+            if (first && per) {
                 uint32_t *ctr = C.rq + q * RQ_STRIDE;
                 if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) m = atomicAdd(ctr, 1u);
             }
-            m = __builtin_amdgcn_readfirstlane(m);
+            if constexpr (NW == 1) {
+                m = __builtin_amdgcn_readfirstlane(m);
+            } else { // both waves take the same item: through LDS
+                if (first) s_item = m;
+                __syncthreads();
+                m = s_item;
+                __syncthreads();
+            }
             if (m < per) return G + q + RQ_N * m;
             ++rq_tries;
         }
@@ -563,7 +592,7 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
         if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
 
-        const LaneRay ray = pixel_ray(R, pix);
+        const LaneRay ray = pixel_ray(R, pix); // NW = 2: both waves hold the same 64 rays
 
         // ---- block cone: axis = mean of the four centre rays, angle = farthest lane ----
         float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
@@ -577,11 +606,12 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
         cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
         const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
 
-        // ---- block cull over the cell's list (ballot compaction, order preserving) ----
+        // ---- block cull over the cell's list (ballot compaction, order preserving; NW = 2: 128 entries per pass, the
+        //      second wave's survivors behind the first's) ----
         __syncthreads(); // previous item's LDS reads are done
         uint32_t cnt = 0;
-        for (uint32_t base = 0; base < n_list; base += 64) {
-            const uint32_t k = base + lane;
+        for (uint32_t base = 0; base < n_list; base += 64 * NW) {
+            const uint32_t k = base + wv * 64 + lane;
             bool keep = false;
             float4 a, bq, ms, alb;
             float q;
@@ -591,14 +621,23 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
                 keep = cone_keeps(cone, a, bq);
             }
             const unsigned long long mask = __ballot(keep);
-            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            uint32_t before = 0, pass_total = (uint32_t)__popcll(mask);
+            if constexpr (NW == 2) {
+                if (lane == 0) s_cnt[wv] = pass_total;
+                __syncthreads();
+                before = wv ? s_cnt[0] : 0u;
+                pass_total = s_cnt[0] + s_cnt[1];
+            }
+            const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
             if (keep && pos < PCAP) { s_A[pos] = a; s_B[pos] = bq; s_M[pos] = ms; s_C[pos] = alb; s_q[pos] = q; }
-            cnt += (uint32_t)__popcll(mask);
+            cnt += pass_total;
+            if constexpr (NW == 2) __syncthreads(); // s_cnt is rewritten by the next pass
         }
         __syncthreads();
 
         const unsigned long long tl1 = O.timeline ? wall_clock64() : 0ull;
-        // ---- lane cull: this ray's own candidates (exact per-ray criterion x > cull_x, no margin needed) ----
+        // ---- lane cull: this ray's own candidates (exact per-ray criterion x > cull_x, no margin needed).  NW = 2: both
+        //      waves count (each needs nl), the first one files the list ----
         uint32_t nl = 0;
         bool fast = cnt <= PCAP;
         if (fast) {
@@ -607,7 +646,7 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
                 const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
                 const float x = sub_ref(a.w, mul_ref(mubar, mubar)) * bq.y;
                 if (!(x > bq.w)) {
-                    if (nl < PL) s_lane[nl * 64 + lane] = (uint8_t)j;
+                    if (nl < PL && wv == 0) s_lane[nl * 64 + lane] = (uint8_t)j;
                     ++nl;
                 }
             }
@@ -619,10 +658,10 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
             // this one.  Which kernel shades a block is a function of the block alone (the two kernels sum in different
             // orders), so the image does not depend on launch heuristics: the host only chooses how LARGE the dense
             // launch is (vrt_hip_api.cpp, render_common).
-            if (lane == 0) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | bi;
+            if (first) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | bi;
             continue;
         }
-        if (O.stats && lane == 0) {
+        if (O.stats && first) {
             atomicAdd(&O.stats[0], (unsigned long long)cnt);
             atomicAdd(&O.stats[1], (unsigned long long)n_list);
             atomicAdd(&O.stats[5], 1ull);
@@ -630,7 +669,7 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
         uint32_t nmax = nl;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
-        if (O.stats) {
+        if (O.stats && wv == 0) {
             unsigned long long tot = nl;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((int)tot, off, 64);
@@ -641,9 +680,25 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables 
         }
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
         float Lr, Lg, Lb, La;
-        shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
-        write_block(Lr, Lg, Lb, La, valid, out);
-        if (O.timeline && lane == 0) {
+        if constexpr (NW == 1) {
+            shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+            write_block(Lr, Lg, Lb, La, valid, out);
+        } else {
+            // emitters: up to 2*EC of them are cut in two halves, one chunk per wave; longer lists alternate chunks of EC
+            if (nmax <= 2u * EC) {
+                const uint32_t h = (nmax + 1) / 2;
+                shade_range<EXP, ERF>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, wv ? h : 0u, wv ? nmax - h : h, Lr, Lg, Lb, La);
+            } else {
+                shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La, wv * EC, 2 * EC);
+            }
+            if (wv == 1) s_L[lane] = make_float4(Lr, Lg, Lb, La);
+            __syncthreads();
+            if (wv == 0) {
+                const float4 o2 = s_L[lane];
+                write_block(Lr + o2.x, Lg + o2.y, Lb + o2.z, La + o2.w, valid, out);
+            }
+        }
+        if (O.timeline && first) {
             unsigned long long *tl = O.timeline + 5 * (size_t)item;
             tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
             const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, 32 bits
@@ -1155,10 +1210,11 @@ void launch_order_dense(const CellGrid &c, hipStream_t st)
 #ifdef VRT_TU_LANES
 template <int EXP, int ERF>
 static void launch_render_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
-                            const RenderTarget &o, uint32_t grid, hipStream_t st)
+                            const RenderTarget &o, uint32_t grid, int nw, hipStream_t st)
 {
     if (grid == 0) return;
-    hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
+    if (nw == 2) hipLaunchKernelGGL((render_kernel<EXP, ERF, 4, 2>), dim3(grid), dim3(128), 0, st, s, t, c, r, o);
+    else hipLaunchKernelGGL((render_kernel<EXP, ERF, 4, 1>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
 }
 
 #endif // VRT_TU_LANES
@@ -1179,9 +1235,9 @@ static void launch_render_t(const SceneTables &s, const TileLists &t, const Cell
 
 #ifdef VRT_TU_LANES
 void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r, const RenderTarget &o,
-                   uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+                   uint32_t grid, int nw, int exp_kind, int erf_kind, hipStream_t st)
 {
-    VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, st);
+    VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, nw, st);
 }
 #else
 

@@ -41,6 +41,9 @@ static const char *const HELP_MSG =
     "  -t, --with-threads N      CPU worker threads of the reference; the GPU grid takes their place\n"
     "  -q, --quiet               the reference's 'no viewer' switch; this build never opens one\n"
     "this build only\n"
+    "      --gpus N              use the first N GPUs (or the list in VRT_HIP_DEVICES): a frame that is written out or\n"
+    "                            timed on its own is split by image tiles and assembled on the first GPU; the frames of\n"
+    "                            an animation that only reports its average are dealt whole to the GPUs in turn (1)\n"
     "      --plane-arrays        upload per-pixel projection-plane points like the reference instead of generating\n"
     "                            rays in the kernel (same image, 12 more bytes per ray)\n"
     "      --cull-eps E          contributions below E are skipped (1e-9); 0 evaluates the reference's full sum\n"
@@ -56,6 +59,7 @@ struct cmd_args_t { // main.cpp:54-184
     u64 thread_count = 1, nr_frames = 1, tiles = 16, mode = 8;
     f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f, table_step = 0.f;
     bool plane_arrays = false;
+    u64 gpus = 1;
     cmd_args_t(int argc, char **argv)
     {
         static struct option opts[] = {
@@ -68,6 +72,7 @@ struct cmd_args_t { // main.cpp:54-184
             { "camera-offset", required_argument, NULL, 'c' }, { "focal-length", required_argument, NULL, 0xfe },
             { "help", no_argument, NULL, 0xff }, { "plane-arrays", no_argument, NULL, 0xfd },
             { "cull-eps", required_argument, NULL, 0xfc }, { "table-step", required_argument, NULL, 0xfb },
+            { "gpus", required_argument, NULL, 0xfa },
             { NULL, 0, NULL, 0 }
         };
         int lidx;
@@ -92,6 +97,7 @@ struct cmd_args_t { // main.cpp:54-184
             case 0xfd: plane_arrays = true; break;
             case 0xfc: cull_eps = strtof(optarg, NULL); break;
             case 0xfb: table_step = strtof(optarg, NULL); break;
+            case 0xfa: gpus = strtoul(optarg, NULL, 10); break;
             case 'm': mode = strtoul(optarg, NULL, 10); if (mode < 1 || mode > 8) mode = 8; break;
             default: break;
             }
@@ -101,6 +107,7 @@ struct cmd_args_t { // main.cpp:54-184
         if (use_grid && infile != nullptr) use_grid = false; // main.cpp:182: a file overrides the grid
         if (tiles == 0) tiles = 1;
         if (nr_frames == 0) nr_frames = 1;
+        if (gpus == 0) gpus = 1;
     }
 };
 
@@ -109,6 +116,100 @@ static double now_ms()
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// --gpus N: the frame loop of main.cpp:257-335 over a vrt_hip_group (csrc/vrt_hip_group.cpp).  Same output lines.
+static int run_on_group(const cmd_args_t &cmd, const std::vector<vrt::gaussian_t> &gaussians, int pack, int ek, int rk)
+{
+    std::vector<int> devices;
+    if (const char *list = getenv("VRT_HIP_DEVICES")) { // e.g. "0,0": two members on one GPU (how the path is tested on one GPU)
+        for (const char *p = list; *p;) {
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)d);
+            p = (*end == ',') ? end + 1 : end;
+        }
+    }
+    if (devices.empty()) for (u64 i = 0; i < cmd.gpus; ++i) devices.push_back((int)i);
+    devices.resize(cmd.gpus, devices.back());
+    // whole frames dealt to the members (no exchange) when no frame has to be in one place; two members per GPU then,
+    // like the two contexts of the single-GPU loop
+    const bool deal_frames = cmd.outfile == nullptr && cmd.nr_frames > 1;
+    if (deal_frames) { const size_t n = devices.size(); for (size_t i = 0; i < n; ++i) devices.push_back(devices[i]); }
+    vrt_hip_group *grp = nullptr;
+    if (vrt_hip_group_create(devices.data(), (int)devices.size(), &grp) != VRT_HIP_OK) {
+        fprintf(stderr, "[ ERROR ]\t%s\n", vrt_hip_group_last_error(nullptr));
+        return EXIT_FAILURE;
+    }
+    const int n = vrt_hip_group_size(grp);
+    auto chk = [&](int rc, const char *what, vrt_hip_ctx *ctx) {
+        if (rc != VRT_HIP_OK) {
+            fprintf(stderr, "[ ERROR ]\t%s: %s\n", what, ctx ? vrt_hip_last_error(ctx) : vrt_hip_group_last_error(grp));
+            exit(EXIT_FAILURE);
+        }
+    };
+    for (int i = 0; i < n; ++i) {
+        vrt_hip_ctx *ctx = vrt_hip_group_ctx(grp, i);
+        chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians", ctx);
+        chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options", ctx);
+        chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step", ctx);
+        if (deal_frames) chk(vrt_hip_set_shard(ctx, 0, 1), "set_shard", ctx); // every member renders whole frames
+    }
+    const u64 width = cmd.w, height = cmd.h;
+    std::vector<u32> image(width * height);
+    vrt::camera_t cam({ 0.f, 0.f, cmd.camera_offset }, { 0.f, 1.f, 0.f }, { 0.f, 0.f, 1.f }, -90.f, 0.f,
+                      cmd.plane_arrays ? width : 1, cmd.plane_arrays ? height : 1, cmd.focal_length);
+    f32 angle = -90.f;
+    cam.orbit(cmd.inital_rot);
+    angle -= cmd.inital_rot;
+    cam.turn(angle, 0.f);
+    const f32 tw = 2.f / cmd.tiles, th = tw;
+    f32 total_time = 0.f;
+    double t_first = 0.0;
+    for (u64 frames = 1;; ++frames) {
+        const f32 origin[3] = { cam.position[0], cam.position[1], cam.position[2] };
+        const double t0 = now_ms();
+        if (frames == 1) t_first = t0;
+        auto set_rays = [&](vrt_hip_ctx *ctx) {
+            if (cmd.plane_arrays)
+                chk(vrt_hip_set_plane(ctx, (u32)width, (u32)height, cam.projection_plane.xs.data(), cam.projection_plane.ys.data(),
+                                      cam.projection_plane.zs.data()), "set_plane", ctx);
+            else
+                chk(vrt_hip_set_camera_view(ctx, (u32)width, (u32)height, cam.view_matrix.data()), "set_camera_view", ctx);
+        };
+        if (deal_frames) {
+            vrt_hip_ctx *ctx = vrt_hip_group_ctx(grp, (int)((frames - 1) % n));
+            set_rays(ctx);
+            chk(vrt_hip_frame(ctx, tw, th, cam.view_matrix.data(), origin, pack, nullptr, 0), "frame", ctx);
+        } else {
+            for (int i = 0; i < n; ++i) set_rays(vrt_hip_group_ctx(grp, i));
+            chk(vrt_hip_group_frame(grp, tw, th, cam.view_matrix.data(), origin, pack, cmd.outfile ? image.data() : nullptr, 1), "group_frame", nullptr);
+        }
+        const f32 frame_time = (f32)(now_ms() - t0);
+        if (cmd.outfile != nullptr) {
+            const std::string of(cmd.outfile);
+            const size_t dot = of.find_last_of('.');
+            const std::string stem = of.substr(0, dot), ext = dot == std::string::npos ? "png" : of.substr(dot + 1);
+            const std::string path = cmd.nr_frames > 1 ? stem + "_" + std::to_string(frames) + "." + ext : stem + "." + ext;
+            if (!png::write_rgba(path.c_str(), (u32)width, (u32)height, image.data(), width * 4))
+                fprintf(stderr, "[ ERROR ]\tcould not write %s\n", path.c_str());
+        }
+        if (cmd.nr_frames == 1) printf("TIME: %g ms\n", frame_time);
+        total_time += frame_time;
+        if (cmd.nr_frames == frames) {
+            chk(vrt_hip_group_sync(grp), "sync", nullptr);
+            if (deal_frames) total_time = (f32)(now_ms() - t_first);
+            if (cmd.nr_frames > 1) printf("AVG. TIME: %g ms (%llu frames)\n", total_time / cmd.nr_frames, (unsigned long long)cmd.nr_frames);
+            break;
+        }
+        const f32 angle_change = cmd.rot / cmd.nr_frames;
+        cam.orbit(angle_change);
+        angle -= angle_change;
+        cam.turn(angle, 0.f);
+    }
+    vrt_hip_group_destroy(grp);
+    return EXIT_SUCCESS;
 }
 
 int main(int argc, char **argv)
@@ -133,6 +234,9 @@ int main(int argc, char **argv)
     int pack = VRT_PACK_TRUNC | VRT_ALPHA_OPAQUE, ek = VRT_EXP_VCL, rk = VRT_ERF_AS;
     if (base_mode == 1) { ek = VRT_EXP_LIBM; rk = VRT_ERF_LIBM; }
     if (base_mode == 4) pack = VRT_PACK_ROUND | (use_tiling ? VRT_ALPHA_COMPUTED : VRT_ALPHA_OPAQUE);
+
+    if (cmd.gpus > 1 && use_tiling) return run_on_group(cmd, gaussians, pack, ek, rk);
+    if (cmd.gpus > 1) fprintf(stderr, "[ INFO ]\t--gpus applies to the tiled modes (5-8): an untiled frame has no tiles to shard; using one GPU\n");
 
     // An animation whose frames are not written out keeps two frames in flight: the frames alternate between two
     // contexts (each has its own HIP stream), so one frame's list kernel overlaps the other's render kernel.

@@ -9,6 +9,9 @@ the copy loop of the reference's simd_render_image (rt.h:388-399).
 """
 import numpy as np
 
+CELL = 32                 # csrc/vrt_kernels.h: second-level cull region = the unit of a sparse shard
+SPARSE_HDR_WORDS = 4      # [0] cells stored, [1] capacity, [2] cells per tile, [3] 0
+
 
 def shard_owner(t, tiles_w, world):
     return (t + t // tiles_w) % world
@@ -118,6 +121,144 @@ class FrameGatherer:
         assemble(b, f) is called on rank 0 for every gathered frame."""
         pending, nfs = [None, None], [0, 0]
         busy = [False, False]
+
+        def finish(b):
+            if pending[b] is not None:
+                pending[b].wait()
+            if self.rank == 0:
+                for f in range(nfs[b]):
+                    assemble(b, f)
+            pending[b], busy[b] = None, False
+
+        F = self.F
+        for i in range((nsteps + F - 1) // F):
+            b, nf = i & 1, min(F, nsteps - i * F)
+            if busy[b]:
+                finish(b)
+            for f in range(nf):
+                render(b, f)
+            nfs[b], pending[b], busy[b] = nf, self.start(b, nf), True
+            if busy[1 - b]:
+                finish(1 - b)
+        for b in (0, 1):
+            if busy[b]:
+                finish(b)
+
+
+# ---- sparse shards (include/vrt_hip.h, "Sparse shards"): only the 32x32 cells that hold something travel ----------------
+def sparse_capacity(table, tile_w, tile_h):
+    """Cells a shard buffer can hold: slots per rank x cells per tile (the same on every rank)."""
+    return table.shape[1] * (-(-tile_w // CELL)) * (-(-tile_h // CELL))
+
+
+def sparse_pixel_offset(cap):
+    return (SPARSE_HDR_WORDS + cap + 3) // 4 * 4
+
+
+def sparse_words(cap):
+    return sparse_pixel_offset(cap) + cap * CELL * CELL
+
+
+def extract_sparse(image, table, rank, tiles_w, tile_w, tile_h, background=0):
+    """The sparse shard rank `rank` would produce from a raster image [H, W] (u32): every cell of its tiles that is not
+    all background, in tile / cell order (the device files them in whatever order its workgroups finish; any order is a
+    valid shard)."""
+    cx, cy = -(-tile_w // CELL), -(-tile_h // CELL)
+    cap = sparse_capacity(table, tile_w, tile_h)
+    out = np.zeros(sparse_words(cap), np.uint32)
+    out[1], out[2] = cap, cx * cy
+    P, n = sparse_pixel_offset(cap), 0
+    for t in table[rank]:
+        if t < 0:
+            continue
+        ty, tx = divmod(int(t), tiles_w)
+        tile = image[ty * tile_h:(ty + 1) * tile_h, tx * tile_w:(tx + 1) * tile_w]
+        for ci in range(cx * cy):
+            y0, x0 = (ci // cx) * CELL, (ci % cx) * CELL
+            cell = np.full((CELL, CELL), background, np.uint32)
+            part = tile[y0:y0 + CELL, x0:x0 + CELL]
+            cell[:part.shape[0], :part.shape[1]] = part
+            if (part != background).any():
+                out[SPARSE_HDR_WORDS + n] = int(t) * cx * cy + ci
+                out[P + n * CELL * CELL: P + (n + 1) * CELL * CELL] = cell.ravel()
+                n += 1
+    out[0] = n
+    return out
+
+
+def scatter_sparse(shards, tiles_w, tile_w, tile_h, height, width, background=0):
+    """Raster image from sparse shards (each a u32 array, full or a prefix): background, then every stored cell."""
+    img = np.full((height, width), background, np.uint32)
+    cx, cy = -(-tile_w // CELL), -(-tile_h // CELL)
+    for sh in shards:
+        sh = np.asarray(sh).view(np.uint32)
+        n, cap = int(sh[0]), int(sh[1])
+        P = sparse_pixel_offset(cap)
+        for s_ in range(n):
+            key = int(sh[SPARSE_HDR_WORDS + s_])
+            t, ci = divmod(key, cx * cy)
+            ty, tx = divmod(t, tiles_w)
+            y0, x0 = ty * tile_h + (ci // cx) * CELL, tx * tile_w + (ci % cx) * CELL
+            hh, ww = min(CELL, (ty + 1) * tile_h - y0), min(CELL, (tx + 1) * tile_w - x0)
+            cell = sh[P + s_ * CELL * CELL: P + (s_ + 1) * CELL * CELL].reshape(CELL, CELL)
+            img[y0:y0 + hh, x0:x0 + ww] = cell[:hh, :ww]
+    return img
+
+
+class SparseFrameGatherer:
+    """FrameGatherer for sparse shards.  A shard's size is data (header word 0), a gather wants equal sizes: per batch the
+    ranks agree on the fullest shard of the batch (one tiny all-reduce(MAX) + one host read) and gather the prefix
+    [0, pixel offset + 1024 * that) of every frame's shard -- 0.8 MB instead of 16 MB per `-g 64 -w 2048` frame.
+
+    words    u32 per shard buffer (vrt_hip_sparse_shard_words(), the same on every rank); cap: its capacity in cells
+    """
+
+    def __init__(self, dist, rank, world, words, cap, frames, device, stage=False):
+        import torch
+        self.dist, self.rank, self.world, self.words, self.cap = dist, rank, world, int(words), int(cap)
+        self.F, self.stage, self.device = max(1, int(frames)), stage, device
+        self.P = sparse_pixel_offset(self.cap)
+        self.shard = [torch.zeros(self.F * self.words, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [None, None]     # rank 0: [world, nf, prefix] of the batch in flight
+        self.prefix = [0, 0]
+        self.bytes_moved = 0
+        self.frames_moved = 0
+
+    def shard_frame(self, b, f):
+        return self.shard[b][f * self.words:(f + 1) * self.words]
+
+    def gathered_shards(self, b, f):
+        """Rank 0: the `world` shard prefixes of frame f of buffer b (tensor views, one per rank)."""
+        return [self.recv[b][q, f] for q in range(self.world)]
+
+    def start(self, b, nf):
+        import torch
+        frames = self.shard[b].view(self.F, self.words)[:nf]
+        most = frames[:, 0].max().reshape(1).to(torch.int64)          # cells of the fullest shard of this batch, this rank
+        if self.stage:
+            most = most.cpu()
+        self.dist.all_reduce(most, op=self.dist.ReduceOp.MAX)
+        prefix = self.P + int(most.item()) * CELL * CELL                # host read: the one synchronisation per batch
+        send = frames[:, :prefix].contiguous()
+        self.prefix[b] = prefix
+        if self.rank == 0:
+            self.recv[b] = torch.empty((self.world, nf, prefix), dtype=torch.int32, device=self.device)
+            self.bytes_moved += (self.world - 1) * nf * prefix * 4
+            self.frames_moved += nf
+        dst = list(self.recv[b].unbind(0)) if self.rank == 0 else None
+        if not self.stage:
+            return self.dist.gather(send, dst, dst=0, async_op=True)
+        host = send.cpu()
+        out = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(host, out, dst=0)
+        if self.rank == 0:
+            for q in range(self.world):
+                dst[q].copy_(out[q])
+        return None
+
+    def run(self, nsteps, render, assemble):
+        """nsteps frames: render(b, f) fills shard_frame(b, f); assemble(b, f) is called on rank 0 for every gathered frame."""
+        pending, nfs, busy = [None, None], [0, 0], [False, False]
 
         def finish(b):
             if pending[b] is not None:

@@ -123,3 +123,79 @@ def test_batched_frame_loop(world, nsteps, frames_per_gather, tmp_path, pkg):
     out = str(tmp_path / "n.npy")
     mp.spawn(_loop_worker, args=(world, _free_port(), out, nsteps, frames_per_gather), nprocs=world, join=True)
     assert int(np.load(out)[0]) == nsteps
+
+
+def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather):
+    """The sparse protocol (sharding.SparseFrameGatherer, what bench.py runs over RCCL for N > 1) on CPU tensors: frames
+    whose lit cells move from frame to frame, tiles that are not a multiple of the 32-px cell, more ranks than lit tiles."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    load_pkg()
+    from sgrt_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tiles_n, tile_w, tile_h = 4, 80, 40           # 3 x 2 cells per tile, the last column / row of cells partial
+        h, w = tiles_n * tile_h, tiles_n * tile_w
+        tab = sharding.shard_table(tiles_n, tiles_n, world)
+        cap = sharding.sparse_capacity(tab, tile_w, tile_h)
+        words = sharding.sparse_words(cap)
+
+        def frame_image(k):                            # a blob that moves with k over a zero background
+            yy, xx = np.mgrid[0:h, 0:w]
+            blob = ((yy - (20 + 9 * k) % h) ** 2 + (xx - (30 + 31 * k) % w) ** 2) < (18 + 3 * (k % 4)) ** 2
+            return np.where(blob, (np.uint32(0x01000000) + (yy * w + xx + k).astype(np.uint32)), np.uint32(0)).astype(np.uint32)
+
+        fg = sharding.SparseFrameGatherer(dist, rank, world, words, cap, frames_per_gather, "cpu")
+        which, counter, frames = {}, [0], []
+
+        def render(b, f):
+            k = counter[0]; counter[0] += 1
+            which[(b, f)] = k
+            sh = sharding.extract_sparse(frame_image(k), tab, rank, tiles_n, tile_w, tile_h)
+            fg.shard_frame(b, f).copy_(torch.from_numpy(sh.view(np.int32)))
+
+        def assemble(b, f):
+            parts = [t.numpy() for t in fg.gathered_shards(b, f)]
+            frames.append((which[(b, f)], sharding.scatter_sparse(parts, tiles_n, tile_w, tile_h, h, w)))
+
+        fg.run(nsteps, render, assemble)
+        if rank == 0:
+            assert [k for k, _ in frames] == list(range(nsteps))
+            for k, fr in frames:
+                np.testing.assert_array_equal(fr, frame_image(k))
+            dense_bytes = (world - 1) * nsteps * tab.shape[1] * tile_w * tile_h * 4
+            np.save(out_path, np.array([len(frames), fg.bytes_moved, dense_bytes]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nsteps,frames_per_gather", [(2, 7, 3), (3, 5, 2), (8, 4, 4)])
+def test_sparse_shard_frame_loop(world, nsteps, frames_per_gather, tmp_path, pkg):
+    out = str(tmp_path / "n.npy")
+    mp.spawn(_sparse_loop_worker, args=(world, _free_port(), out, nsteps, frames_per_gather), nprocs=world, join=True)
+    n, moved, dense = np.load(out)
+    assert int(n) == nsteps
+    assert moved < dense            # fewer bytes travel than the compact shards would take
+
+
+def test_sparse_shard_layout_round_trip(pkg):
+    """extract_sparse / scatter_sparse (host mirror of RenderTarget::sparse and scatter_sparse_kernel): any image comes
+    back, for tile sizes that are and are not multiples of the cell, for every world size."""
+    from sgrt_amd import sharding
+    rng = np.random.default_rng(5)
+    for tiles_n, tile_w, tile_h, world in [(4, 64, 64, 1), (4, 64, 64, 3), (2, 100, 33, 2), (3, 32, 96, 8), (1, 70, 70, 2)]:
+        h, w = tiles_n * tile_h, tiles_n * tile_w
+        img = np.zeros((h, w), np.uint32)
+        for _ in range(6):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            img[y:y + int(rng.integers(1, 40)), x:x + int(rng.integers(1, 40))] = rng.integers(1, 2 ** 32, dtype=np.uint64).astype(np.uint32)
+        tab = sharding.shard_table(tiles_n, tiles_n, world)
+        shards = [sharding.extract_sparse(img, tab, r, tiles_n, tile_w, tile_h) for r in range(world)]
+        assert all(int(s[1]) == sharding.sparse_capacity(tab, tile_w, tile_h) for s in shards)
+        np.testing.assert_array_equal(sharding.scatter_sparse(shards, tiles_n, tile_w, tile_h, h, w), img)
+        # a prefix that just covers the stored cells is enough (what the gather ships)
+        cut = [s[:sharding.sparse_pixel_offset(int(s[1])) + int(s[0]) * 1024] for s in shards]
+        np.testing.assert_array_equal(sharding.scatter_sparse(cut, tiles_n, tile_w, tile_h, h, w), img)

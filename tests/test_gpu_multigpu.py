@@ -1,0 +1,151 @@
+"""GPU tests of the multi-GPU path on ONE GPU: several contexts / group members on device 0 stand for the ranks.
+
+  - sparse shards (vrt_hip_frame_sparse_device) of 2, 3 and 8 "ranks", scattered by vrt_hip_scatter_sparse_device, give
+    the single-context frame bit for bit -- sparse scenes, dense scenes (cells of the dense queue), table mode,
+    tile sizes that are not a multiple of the 32-px cell, more ranks than tiles, both background conventions;
+  - the device-side shard layout is the one sharding.py mirrors on the host (the gloo tests use that mirror);
+  - vrt_hip_group (what `volumetric-ray-tracer --gpus N` drives) with members on one device; frames back to back;
+  - the CLI with --gpus 2 (VRT_HIP_DEVICES=0,0): same PNG as one GPU, frame-parallel animation runs;
+  - bench.py's N = 2 flow over gloo on one GPU.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "bin")
+OBJ = os.path.join(GOLDEN, "test-objects")
+
+
+def single_frame(pkg, r, g, cam, w, h, tiles_n, pack, table=0.0):
+    r.set_gaussians(g)
+    r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    r.set_table_step(table)
+    r.set_shard(0, 1)
+    r.set_camera_view(w, h, cam.view)
+    r.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, cam.view)
+    img, _ = r.render(cam.position, pack, want_radiance=False)
+    return img
+
+
+@pytest.mark.parametrize("scene_name,w,h,tiles_n,world,rot,table", [
+    ("g64", 1024, 1024, 16, 2, 0.0, 0.0),        # sparse scene: 95 % background
+    ("g64", 1024, 1024, 16, 8, 47.0, 0.0),       # seen at an angle: dense cells appear
+    ("monkey", 512, 512, 16, 3, 20.0, 0.0),      # dense kernel for most cells
+    ("monkey", 512, 512, 16, 2, 20.0, 0.12),     # table kernel + exact kernel behind it
+    ("cube", 200, 136, 5, 3, 123.0, 0.0),        # 40 x 27-px tiles: partial cells; truncated tile size
+    ("g4", 96, 96, 2, 8, 0.0, 0.0),              # more ranks than tiles
+])
+@pytest.mark.parametrize("pack_name", ["mode8", "opaque"])
+def test_sparse_shards_assemble_to_the_single_gpu_frame(pkg, renderer, scene_name, w, h, tiles_n, world, rot, table, pack_name):
+    import torch
+    from sgrt_amd import scene, sharding
+    g = {"g64": lambda: scene.grid_scene(64), "g4": lambda: scene.grid_scene(4),
+         "monkey": lambda: scene.read_obj(os.path.join(OBJ, "monkey.obj")),
+         "cube": lambda: scene.read_obj(os.path.join(OBJ, "cube.obj"))}[scene_name]()
+    pack = pkg.PACK_ROUND | (pkg.ALPHA_COMPUTED if pack_name == "mode8" else pkg.ALPHA_OPAQUE)
+    cam, _ = scene.cli_camera(w, h, initial_rot=rot)
+    want = single_frame(pkg, renderer, g, cam, w, h, tiles_n, pack, table)
+    st = torch.cuda.current_stream().cuda_stream
+    ranks, shards = [], []
+    try:
+        for rk in range(world):
+            r = pkg.Renderer(0)
+            ranks.append(r)
+            r.set_gaussians(g)
+            r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+            r.set_table_step(table)
+            r.set_camera_view(w, h, cam.view)
+            r.set_shard(rk, world)
+            r.tile_gaussians_device(2.0 / tiles_n, 2.0 / tiles_n, cam.view, st)
+            words = r.sparse_shard_words()
+            buf = torch.full((words,), -1, dtype=torch.int32, device="cuda")     # garbage: only what is written may be used
+            r.frame_sparse_call(2.0 / tiles_n, 2.0 / tiles_n, cam.view, cam.position, pack)(buf.data_ptr(), st)
+            shards.append(buf)
+        out = torch.full((w * h,), 0x55, dtype=torch.int32, device="cuda")
+        ranks[0].scatter_sparse_device([b.data_ptr() for b in shards], pack, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint32).reshape(h, w)
+        np.testing.assert_array_equal(got, want)
+        # the device layout is the one the host mirror reads (sharding.scatter_sparse), and the cells partition the lit area
+        host = [b.cpu().numpy().view(np.uint32) for b in shards]
+        tile_w, tile_h = int(np.float32(w) * np.float32(2.0 / tiles_n) / np.float32(2.0)), int(np.float32(h) * np.float32(2.0 / tiles_n) / np.float32(2.0))
+        bg = 0 if pack_name == "mode8" else 0xFF000000
+        if tile_w * tiles_n == w and tile_h * tiles_n == h:
+            np.testing.assert_array_equal(sharding.scatter_sparse(host, tiles_n, tile_w, tile_h, h, w, background=bg), want)
+        stored = sum(int(s[0]) for s in host)
+        caps = {int(s[1]) for s in host if int(s[1])}
+        assert len(caps) <= 1                                        # one capacity for the whole job
+        keys = np.concatenate([s[4:4 + int(s[0])] for s in host])
+        assert len(np.unique(keys)) == stored                        # no cell stored twice
+        if scene_name == "g64" and rot == 0.0:
+            assert stored * 1024 < 0.2 * w * h                       # the point of the format: most of the frame never travels
+    finally:
+        for r in ranks:
+            r.close()
+
+
+def test_group_frames_on_one_device(pkg, renderer):
+    """vrt_hip_group with 1, 2 and 3 members on device 0: group_frame == the single-context frame; a second frame with
+    another camera enqueued right behind the first (shard buffers are reused: the group orders that itself)."""
+    from sgrt_amd import scene
+    w = h = 768
+    g = scene.grid_scene(64)
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    cams = [scene.cli_camera(w, h, initial_rot=a)[0] for a in (0.0, 33.0, 0.0)]
+    want = [single_frame(pkg, renderer, g, c, w, h, 16, pack) for c in cams]
+    for n in (1, 2, 3):
+        grp = pkg.Group([0] * n)
+        try:
+            for m in grp.members:
+                m.set_gaussians(g)
+                m.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+            for c, ref in zip(cams, want):
+                for m in grp.members:
+                    m.set_camera_view(w, h, c.view)
+                grp.frame(2 / 16, 2 / 16, c.view, c.position, pack, want_image=False, wait=False)     # not waited for
+                got = grp.frame(2 / 16, 2 / 16, c.view, c.position, pack)
+                np.testing.assert_array_equal(got, ref)
+        finally:
+            grp.close()
+
+
+def test_cli_gpus_flag(tmp_path):
+    """--gpus 2 with both members on GPU 0: the tile-sharded single frame writes the PNG one GPU writes; the animation
+    without output deals whole frames to the members and prints the average."""
+    from PIL import Image
+    exe = os.path.join(BIN, "volumetric-ray-tracer")
+    env = dict(os.environ, VRT_HIP_DEVICES="0,0")
+    for args in (["-g", "16", "-w", "512", "-i", "20"], ["-f", os.path.join(OBJ, "sphere.obj"), "-w", "256", "--tiles", "8"]):
+        a = subprocess.run([exe, *args, "-q", "-o", "one.png"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        b = subprocess.run([exe, *args, "-q", "--gpus", "2", "-o", "two.png"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+        assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+        assert b.stdout.startswith("TIME: ")
+        np.testing.assert_array_equal(np.array(Image.open(tmp_path / "one.png")), np.array(Image.open(tmp_path / "two.png")))
+    p = subprocess.run([exe, "-g", "64", "-w", "1024", "-q", "--gpus", "2", "--frames", "24"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode == 0 and p.stdout.startswith("AVG. TIME: ") and "(24 frames)" in p.stdout, p.stdout + p.stderr
+    q = subprocess.run([exe, "-g", "8", "-w", "128", "-q", "--gpus", "2", "--frames", "3", "-o", "f.png"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert q.returncode == 0 and all((tmp_path / f"f_{k}.png").exists() for k in (1, 2, 3)), q.stderr
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    """bench.py's N = 2 flow (sparse shards -> gather -> scatter on rank 0) with the gloo backend, both ranks on GPU 0:
+    the assembled frame must equal the single-GPU frame (bench.py checks it and reports it in its JSON line)."""
+    env = dict(os.environ, VRT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--gather-frames", "4",
+           "--width", "1024", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["frame_equals_single_gpu_frame"] is True
+    assert res["config"]["shard_transport"]["bytes_per_frame"] < 0.25 * 1024 * 1024 * 4

@@ -14,7 +14,10 @@ B,G,R,A byte order of the PNG (main.cpp:306).
 
 CPU tests: the ORACLE (oracle/vrt_oracle.c) and the CPU baseline port (oracle/vrt_cpu_simd.*) against the PNG on seeded
 pixel / tile samples.  GPU tests: the HIP path, full frame, through the Python binding and through the CLI binary.
-The cube image of the thesis could not be matched to a command line (profiles/r02_thesis_png_fit_cube.md) and is not used.
+
+The second image, `thesis/images/cube.png`, is `-f test-objects/cube.obj -w 1024 --focal-length 1.5 -i 30` (386 Gaussians of
+sigma 0.15, the camera turned by 30 degrees: profiles/r02_thesis_png_fit_cube.md) -- the same chain at another focal
+length and with the orbit step / camera_t::turn of main.cpp:252-255 in it.
 """
 import os
 import subprocess
@@ -27,12 +30,14 @@ from conftest import GOLDEN, ROOT
 W = H = 1024
 FOCAL = 1.7
 OBJ = os.path.join(GOLDEN, "test-objects", "teapot.obj")
+CUBE_OBJ = os.path.join(GOLDEN, "test-objects", "cube.obj")
+CUBE_FOCAL, CUBE_ROT = 1.5, 30.0
 BIN = os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "bin")
 
 
-def thesis_png():
+def thesis_png(name="teapot"):
     from PIL import Image
-    png = np.array(Image.open(os.path.join(GOLDEN, "thesis", "teapot.png")))
+    png = np.array(Image.open(os.path.join(GOLDEN, "thesis", f"{name}.png")))
     assert png.shape == (H, W, 4) and png.dtype == np.uint8
     return png.astype(np.int16)
 
@@ -97,6 +102,38 @@ def test_cpu_baseline_port_reproduces_the_reference_image(oracle):
     assert n > 600                                                               # the sampled rows are on the teapot
 
 
+def test_oracle_reproduces_the_rotated_cube_image(oracle):
+    """thesis/images/cube.png: another object, sigma, focal length -- and a camera that was turned (-i 30): the orbit step
+    (glm::rotate about +Y), camera_t::turn and the view matrix of a rotated pose are in this one."""
+    png = thesis_png("cube").reshape(-1, 4)
+    g = oracle.read_obj(CUBE_OBJ)
+    assert len(g) == 386 and float(g["sigma"][0]) == np.float32(0.15)
+    cam, angle = oracle.cli_camera(W, H, focal=CUBE_FOCAL, initial_rot=CUBE_ROT)
+    assert angle[0] == np.float32(-120.0)
+    tiles = oracle.tile_gaussians(2 / 16, 2 / 16, g, oracle.camera_view(cam))
+    pix = sample_pixels(thesis_png("cube"), 900, seed=386)
+    img, _ = oracle.render(W, H, oracle.camera_plane(cam), cam.position[:], g, tiles, pixels=pix)
+    d = np.abs(file_bytes(img[pix]) - png[pix])
+    assert d.max() <= 1, (int(d.max()), pix[np.argmax(d.max(1))])
+    assert (d == 0).mean() >= 0.97
+
+
+@pytest.mark.gpu
+def test_gpu_frame_is_the_rotated_cube_image(pkg, renderer):
+    from sgrt_amd import scene
+    png = thesis_png("cube")
+    g = scene.read_obj(CUBE_OBJ)
+    cam, _ = scene.cli_camera(W, H, focal=CUBE_FOCAL, initial_rot=CUBE_ROT)
+    renderer.set_gaussians(g)
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    renderer.set_camera_view(W, H, cam.view)
+    renderer.tile_gaussians(2 / 16, 2 / 16, cam.view)
+    img, _ = renderer.render(cam.position, pkg.PACK_ROUND | pkg.ALPHA_COMPUTED, want_radiance=False)
+    d = np.abs(file_bytes(img).reshape(H, W, 4) - png)
+    assert d.max() <= 1
+    assert (d == 0).mean() >= 0.99
+
+
 @pytest.mark.gpu
 def test_gpu_frame_is_the_reference_image(pkg, renderer):
     """The HIP path, full frame, product camera: every channel value within one u8 step of the reference's PNG and
@@ -131,3 +168,9 @@ def test_cli_writes_the_reference_image(tmp_path):
     got = np.array(Image.open(out)).astype(np.int16)
     d = np.abs(got - thesis_png())
     assert d.max() <= 1 and (d == 0).mean() >= 0.995
+    out2 = tmp_path / "cube.png"
+    p = subprocess.run([os.path.join(BIN, "volumetric-ray-tracer"), "-q", "-f", CUBE_OBJ, "-w", "1024", "--focal-length", "1.5", "-i", "30",
+                        "-o", str(out2)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    d = np.abs(np.array(Image.open(out2)).astype(np.int16) - thesis_png("cube"))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.99

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#define N_IT 2048
+#define N_IT 32768
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int OP>
@@ -52,6 +52,28 @@ __global__ void k(float *out, float a, float b)
         } else if (OP == 11) { // v_xor_b32 (VOP2) x8
             asm volatile("v_xor_b32 %0, %8, %0\n v_xor_b32 %1, %8, %1\n v_xor_b32 %2, %8, %2\n v_xor_b32 %3, %8, %3\n v_xor_b32 %4, %8, %4\n v_xor_b32 %5, %8, %5\n v_xor_b32 %6, %8, %6\n v_xor_b32 %7, %8, %7\n"
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 13) { // v_fma_f32 with |abs| modifier and an SGPR operand (the erf polynomial's form) x8
+            asm volatile("v_fma_f32 %0, |%0|, %8, %9\n v_fma_f32 %1, |%1|, %8, %9\n v_fma_f32 %2, |%2|, %8, %9\n v_fma_f32 %3, |%3|, %8, %9\n"
+                         "v_fma_f32 %4, |%4|, %8, %9\n v_fma_f32 %5, |%5|, %8, %9\n v_fma_f32 %6, |%6|, %8, %9\n v_fma_f32 %7, |%7|, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b));
+        } else if (OP == 14) { // v_fmamk_f32 (32-bit literal) x8
+            asm volatile("v_fmamk_f32 %0, %0, 0x3f7fbe77, %8\n v_fmamk_f32 %1, %1, 0x3f7fbe77, %8\n v_fmamk_f32 %2, %2, 0x3f7fbe77, %8\n v_fmamk_f32 %3, %3, 0x3f7fbe77, %8\n"
+                         "v_fmamk_f32 %4, %4, 0x3f7fbe77, %8\n v_fmamk_f32 %5, %5, 0x3f7fbe77, %8\n v_fmamk_f32 %6, %6, 0x3f7fbe77, %8\n v_fmamk_f32 %7, %7, 0x3f7fbe77, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+        } else if (OP == 15) { // v_mov_b32 x8
+            asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+        } else if (OP == 16) { // v_cmp_lt_f32 + v_cndmask_b32 pairs x4
+            asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %9, vcc\n v_cmp_lt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %9, vcc\n"
+                         "v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %9, vcc\n v_cmp_lt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+        } else if (OP == 17) { // v_add_f32 (VOP2) x8
+            asm volatile("v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 18) { // v_fma_f32, all three sources in ONE register bank (v0, v4, v8 style: operands 4 apart)
+            asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
+                         "v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
         } else if (OP == 12) { // v_pk_mul_f32 x8
             asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa));
@@ -86,7 +108,7 @@ void run(const char *name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 3}) {
         run<0>("v_fma_f32 indep", w);
         run<4>("v_fma_f32 dependent", w);
         run<1>("v_pk_fma_f32", w);
@@ -100,6 +122,12 @@ int main()
         run<10>("v_sub_f32", w);
         run<11>("v_xor_b32", w);
         run<12>("v_pk_mul_f32", w);
+        run<13>("v_fma |abs| + sgpr", w);
+        run<14>("v_fmamk literal", w);
+        run<15>("v_mov_b32", w);
+        run<16>("v_cmp + v_cndmask (x4)", w);
+        run<17>("v_add_f32", w);
+        run<18>("v_fma same-register srcs", w);
     }
     return 0;
 }
