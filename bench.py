@@ -7,7 +7,7 @@ Metric (BASELINE.json): Mrays/sec (whole node) + ms/frame, 2048^2 image, 64x64 G
 A step = one frame = what the reference times as `TIME:` (main.cpp:260-296): tile binning of all
 Gaussians + render (+ for N > 1: RCCL gather of the tile shards to rank 0 + assembly into raster
 order).  Inputs (scene tables, camera) are resident in HBM before the timed region starts.
-N = 1 keeps two frames in flight (two library contexts on two HIP streams, --frames-in-flight);
+N = 1 keeps three frames in flight (three library contexts on three HIP streams, --frames-in-flight);
 the strictly serial figures are reported next to the headline under "serial".
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=16)
     ap.add_argument("--cull-eps", type=float, default=1e-9)
     ap.add_argument("--gather-frames", type=int, default=16, help="N > 1: frames per RCCL gather (one collective per batch)")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial frames")
     ap.add_argument("--parallel", choices=["tiles", "frames"], default="tiles",
                     help="N > 1: 'tiles' = one frame's tiles sharded over the ranks + gather (the headline, SURVEY 8e); 'frames' = "
@@ -194,7 +194,7 @@ def main():
     tw = th = 2.0 / args.tiles
     pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
 
-    # N = 1: the frames alternate between `--frames-in-flight` library contexts, each on its own HIP stream (default 2):
+    # N = 1: the frames alternate between `--frames-in-flight` library contexts, each on its own HIP stream (default 3):
     # frame k+1's list kernel and the head of its render kernel run while frame k's render kernel drains -- the
     # double-buffered frame loop of any renderer.  Every frame does all of its work; the strictly serial figures are
     # measured after the timed region and reported next to the headline ("serial").  N > 1: one context per rank
@@ -388,7 +388,7 @@ def main():
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             # ms/frame of the metric = what ONE caller of the vrt:: API waits for a frame (strictly serial frames on one
             # context, measured after the timed region); ms_per_step is the timed loop's wall time per step, which with
-            # two frames in flight is a throughput figure
+            # several frames in flight is a throughput figure
             "ms_per_frame": serial_ms if solo else ms_per_step,
             "higher_is_better": True, "scaling": "weak" if (solo and world > 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"-g {args.grid} -w {w} (tiles {args.tiles}, mode-8 packing, cull_eps {args.cull_eps:g}, "
@@ -404,16 +404,15 @@ def main():
                          "frac": render_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_from": (valu.get("from") if traffic is not None else None),
                          "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": render_bytes,
-                         # an event pair with nothing between reads ~4.6 us on this stack: rocprofv3's kernel duration
-                         # (profiles/) is the event figure minus that.  `achieved` uses the raw (larger) event figure.
-                         "event_pair_overhead_ms": kt["dense_ms"] if st["dense_blocks"] == 0 else None,
+                         # (an event pair with nothing between reads ~5 us on this stack -- measured in round 1 on an empty
+                         # launch slot; rocprofv3's kernel durations under profiles/ are the event figures minus that)
                          # strictly serial frames, after the timed region: four events per frame
                          "launch_sequence_ms": {"lists": kt["lists_ms"], "render_kernel": kt["render_serial_ms"],
                                                 "render_dense_kernel": kt["dense_ms"]},
                          "frame": {"algorithmic_bytes": frame_bytes, "ms": frame_ms, "achieved": frame_gbs,
                                    "frac": frame_gbs / HBM_PEAK_GBS, "traffic": traffic_frame},
                          "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4): see valu; "
-                                 "traffic = WRITE_SIZE + raw FETCH_SIZE of separate PMC passes (profiles/); with two frames "
+                                 "traffic = WRITE_SIZE + raw FETCH_SIZE of separate PMC passes (profiles/); with several frames "
                                  "in flight kernel_ms is the duration of a launch that shares the GPU with the other "
                                  "context's kernels (launch_sequence_ms: the same kernels alone)"},
             # the same loop with one context: frame k+1 starts when frame k is done

@@ -13,6 +13,16 @@ constexpr float SQRT_2_PI = 0.7978845608028654f;
 constexpr float INV_SQRT_2_PI = 1.f / SQRT_2_PI;
 constexpr float SQRT_2 = 1.41421356237309504880f;
 
+// A wave-uniform constant the compiler would keep in an SGPR, moved to a VGPR: on gfx950 a VALU instruction with an SGPR
+// source issues in 4.4 cycles (3 waves per SIMD) where the same instruction on VGPRs, inline constants or a literal takes
+// 2.8-3.2 (tools/ubench/valu.hip, profiles/r02_valu_ops.txt).  The empty asm is opaque to the compiler (no
+// rematerialisation into an SGPR) but free of side effects (hoisted out of loops).
+__device__ __forceinline__ float pin_vgpr(float c)
+{
+    asm("" : "+v"(c));
+    return c;
+}
+
 // exp(x) to ~1 ulp on the quarter-rate v_exp_f32: 2^(x*log2e) with the product's rounding
 // error and the low part of log2e folded back in as a first-order correction.
 // Stands for expf (rt.h:32 default) and vcl_exp (approx.h:91-106), both ~1 ulp.
@@ -184,6 +194,32 @@ __device__ __forceinline__ float verf(float x)
 // |x| from which the variant returns EXACTLY +-1.0f (used to skip saturated terms without changing a bit):
 //   A&S: 1 - rcp(p^4) rounds to 1 once p^4 > 2^25, i.e. |x| >= 5.46; erff: erfc(4.2) = 2.9e-9 << 2^-25;
 //   the splines and the Taylor form clamp explicitly (approx.cpp:11,24,47,75-76).
+// The erf of the hot loops, with its constants where the hardware reads them fastest.  On gfx950 a VALU instruction with
+// an SGPR source operand issues in 4.4 cycles (3 waves per SIMD) where the same instruction on VGPRs, inline constants
+// or a literal takes 2.8-3.2 (tools/ubench/valu.hip, profiles/r02_valu_ops.txt); the compiler keeps the four
+// Abramowitz-Stegun coefficients in SGPRs (a VOP3 fma cannot carry a literal on this ISA), which costs the polynomial
+// 6 cycles of its 17 per term.  Pinning them in VGPRs (an empty asm the compiler cannot see through) makes the four
+// fmas full-rate (pin_vgpr above).  Same operations, same order, same results as erf_as().
+template <int ERF>
+struct ErfEval {
+    __device__ __forceinline__ float operator()(float x) const { return verf<ERF>(x); }
+};
+template <>
+struct ErfEval<VRT_ERF_AS> {
+    float c3, c2, c1, c0;
+    __device__ __forceinline__ ErfEval() : c3(pin_vgpr(0.078108f)), c2(pin_vgpr(0.000972f)), c1(pin_vgpr(0.230389f)), c0(pin_vgpr(0.278393f)) {}
+    __device__ __forceinline__ float operator()(float x) const
+    {
+        const float t = __builtin_fabsf(x);
+        float p = __builtin_fmaf(c3, t, c2);
+        p = __builtin_fmaf(p, t, c1);
+        p = __builtin_fmaf(p, t, c0);
+        p = __builtin_fmaf(p, t, 1.0f);
+        const float p2 = p * p;
+        return __builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p2 * p2), x);
+    }
+};
+
 template <int ERF>
 __host__ __device__ constexpr float erf_saturation()
 {

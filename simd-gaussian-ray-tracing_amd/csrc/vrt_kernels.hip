@@ -130,6 +130,7 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
 {
     Lr = Lg = Lb = La = 0.f;
     if (n == 0) return;
+    const ErfEval<ERF> erf;
 
     for (uint32_t i0 = i_start; i0 < n; i0 += i_step) {
         // emitter chunk set-up
@@ -158,7 +159,7 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
             const float4 b = uload(S.gB, idx);
             const float A = b.z * vexp<EXP>(-(d2 * b.y));
             const float m = mubar * b.x;
-            const float E = verf<ERF>(-m); // Erf(-mubar_j / (sqrt2 sigma_j)), rt.h:122
+            const float E = erf(-m); // Erf(-mubar_j / (sqrt2 sigma_j)), rt.h:122
 #pragma unroll
             for (int e = 0; e < EC; ++e) {
                 const float base = __builtin_fmaf(e_mubar[e], b.x, -m); // (mubar_i - mubar_j) r_j
@@ -169,7 +170,7 @@ __device__ __forceinline__ void shade_list(const SceneTables &S, const uint32_t 
                     // rt.h:124: T += sigma cbar K (erf1 - erf2).  Summing the per-term DIFFERENCE like the
                     // reference (not C - sum A erf2) keeps the running sum small in optically thick scenes,
                     // where saturated pairs cancel exactly.
-                    acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
+                    acc[e][k] = __builtin_fmaf(A, E - erf(x), acc[e][k]);
                 }
             }
         }
@@ -217,6 +218,7 @@ __device__ __forceinline__ void shade_chunk(const float4 *s_A, const float4 *s_B
                                             uint32_t nmax, uint32_t lane, const LaneRay &ray, uint32_t i0, float &Lr,
                                             float &Lg, float &Lb, float &La)
 {
+    const ErfEval<ERF> erf;
     float e_mubar[EC], e_sigma[EC];
     uint32_t e_li[EC];
 #pragma unroll
@@ -247,7 +249,7 @@ __device__ __forceinline__ void shade_chunk(const float4 *s_A, const float4 *s_B
         const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
         const float A = vj ? cb.z * vexp<EXP>(-(d2 * cb.y)) : 0.f;
         const float m = mubar * cb.x;
-        const float E = verf<ERF>(-m);
+        const float E = erf(-m);
 #pragma unroll
         for (int e = 0; e < EC; ++e) {
             const float base = __builtin_fmaf(e_mubar[e], cb.x, -m);
@@ -255,7 +257,7 @@ __device__ __forceinline__ void shade_chunk(const float4 *s_A, const float4 *s_B
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const float x = __builtin_fmaf((float)(k - 4), step, base);
-                acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
+                acc[e][k] = __builtin_fmaf(A, E - erf(x), acc[e][k]);
             }
         }
     }
@@ -592,7 +594,9 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
         if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
 
-        const LaneRay ray = pixel_ray(R, pix); // NW = 2: both waves hold the same 64 rays
+        LaneRay ray = pixel_ray(R, pix); // NW = 2: both waves hold the same 64 rays
+        // the origin is wave-uniform (SGPRs): as a VGPR operand the 15 adds per emitter of the emission issue at full rate
+        ray.ox = pin_vgpr(ray.ox); ray.oy = pin_vgpr(ray.oy); ray.oz = pin_vgpr(ray.oz);
 
         // ---- block cone: axis = mean of the four centre rays, angle = farthest lane ----
         float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
@@ -748,6 +752,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
     const uint64_t npix = (uint64_t)R.width * R.height;
     constexpr float SAT = erf_saturation<ERF>();
     constexpr float SAT_M = SAT + 1e-3f; // the range bounds are re-associated forms of the arguments: keep a margin
+    const ErfEval<ERF> erf;
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
     if (C.feedback && blockIdx.x == 0 && tid == 0) { // launch feedback: how much this frame had for this kernel
         __hip_atomic_store(&C.feedback[2], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
                     const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
                     if (SKIP && __all(front && lo >= SAT_M)) { common = __builtin_fmaf(A, -2.f, common); ++n_visit_common; continue; }
                     ++n_visit_full;
-                    const float E = verf<ERF>(-m);
+                    const float E = erf(-m);
 #pragma unroll
                     for (int e = 0; e < EC; ++e) {
                         const float base = __builtin_fmaf(e_mubar[e], cb.x, -m);
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
 #pragma unroll
                         for (int k = 0; k < 5; ++k) {
                             const float x = __builtin_fmaf((float)(k - 4), step, base);
-                            acc[e][k] = __builtin_fmaf(A, E - verf<ERF>(x), acc[e][k]);
+                            acc[e][k] = __builtin_fmaf(A, E - erf(x), acc[e][k]);
                         }
                     }
                 }
@@ -984,6 +989,7 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
                                                                RenderTarget O)
 {
     constexpr int DW = 16, TC = 512, G = 160, NPW = G / DW, EC = 4;
+    const ErfEval<ERF> erf;
     struct Lds {
         union {
             struct { float4 A[TC], B[TC]; } rows; // 16 KB: the survivors' parameter rows, in list order ...
@@ -1110,9 +1116,9 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
                 const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
                 const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
                 const float m = mubar * cb.x;
-                const float E = verf<ERF>(-m);
+                const float E = erf(-m);
 #pragma unroll
-                for (int i = 0; i < NPW; ++i) acc[i] = __builtin_fmaf(A, E - verf<ERF>(__builtin_fmaf(s_g[i], cb.x, -m)), acc[i]);
+                for (int i = 0; i < NPW; ++i) acc[i] = __builtin_fmaf(A, E - erf(__builtin_fmaf(s_g[i], cb.x, -m)), acc[i]);
             }
 #pragma unroll
             for (int i = 0; i < NPW; ++i) lds.tab[wave + DW * i][lane] = acc[i];

@@ -74,6 +74,35 @@ __global__ void k(float *out, float a, float b)
             asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
                          "v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n"
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+        } else if (OP == 19) { // v_fma_f32 with |abs| modifier, all VGPR x8
+            asm volatile("v_fma_f32 %0, |%0|, %8, %9\n v_fma_f32 %1, |%1|, %8, %9\n v_fma_f32 %2, |%2|, %8, %9\n v_fma_f32 %3, |%3|, %8, %9\n"
+                         "v_fma_f32 %4, |%4|, %8, %9\n v_fma_f32 %5, |%5|, %8, %9\n v_fma_f32 %6, |%6|, %8, %9\n v_fma_f32 %7, |%7|, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        } else if (OP == 20) { // v_fma_f32 with an SGPR operand, no modifier x8
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b));
+        } else if (OP == 21) { // v_pk_fma_f32 with an SGPR-pair operand x8
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(pa), "v"(pb));
+        } else if (OP == 22) { // v_pk_add_f32 x8
+            asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa));
+        } else if (OP == 23) { // v_pk_fma_f32, sources 1 and 2 broadcast from their low halves (op_sel_hi) x8
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %1, %1, %8, %9 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %2, %2, %8, %9 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %3, %3, %8, %9 op_sel_hi:[1,0,0]\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %5, %5, %8, %9 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %6, %6, %8, %9 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %7, %7, %8, %9 op_sel_hi:[1,0,0]\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa), "v"(pb));
+        } else if (OP == 24) { // v_and_b32 (VOP2) x8
+            asm volatile("v_and_b32 %0, %8, %0\n v_and_b32 %1, %8, %1\n v_and_b32 %2, %8, %2\n v_and_b32 %3, %8, %3\n v_and_b32 %4, %8, %4\n v_and_b32 %5, %8, %5\n v_and_b32 %6, %8, %6\n v_and_b32 %7, %8, %7\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 25) { // v_fmaak_f32 (VOP2: a*b + literal) x8
+            asm volatile("v_fmaak_f32 %0, %0, %8, 0x3e6bee59\n v_fmaak_f32 %1, %1, %8, 0x3e6bee59\n v_fmaak_f32 %2, %2, %8, 0x3e6bee59\n v_fmaak_f32 %3, %3, %8, 0x3e6bee59\n"
+                         "v_fmaak_f32 %4, %4, %8, 0x3e6bee59\n v_fmaak_f32 %5, %5, %8, 0x3e6bee59\n v_fmaak_f32 %6, %6, %8, 0x3e6bee59\n v_fmaak_f32 %7, %7, %8, 0x3e6bee59\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 26) { // v_fmac_f32 (VOP2: d += a*b) x8
+            asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
         } else if (OP == 12) { // v_pk_mul_f32 x8
             asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa));
@@ -108,7 +137,7 @@ void run(const char *name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {1, 3}) {
+    for (int w : {3}) {
         run<0>("v_fma_f32 indep", w);
         run<4>("v_fma_f32 dependent", w);
         run<1>("v_pk_fma_f32", w);
@@ -128,6 +157,14 @@ int main()
         run<16>("v_cmp + v_cndmask (x4)", w);
         run<17>("v_add_f32", w);
         run<18>("v_fma same-register srcs", w);
+        run<19>("v_fma |abs| all VGPR", w);
+        run<20>("v_fma with SGPR src", w);
+        run<21>("v_pk_fma SGPR-pair src", w);
+        run<22>("v_pk_add_f32", w);
+        run<23>("v_pk_fma op_sel bcast", w);
+        run<24>("v_and_b32", w);
+        run<25>("v_fmaak literal", w);
+        run<26>("v_fmac_f32 (VOP2)", w);
     }
     return 0;
 }
