@@ -90,10 +90,23 @@ for case in range(ncase):
         out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
         r.assemble_shards_device(torch.cat(shards).data_ptr(), out.data_ptr(), st)
         torch.cuda.synchronize()
+        # the same ranks as SPARSE shards (only the cells that hold something), scattered over a cleared frame
+        sparse = []
+        for rank in range(world):
+            r.set_shard(rank, world)
+            r.tile_gaussians_device(2.0 / tiles_n, 2.0 / tiles_n, view, st)
+            buf = torch.full((max(r.sparse_shard_words(), 4),), -1, dtype=torch.int32, device="cuda")
+            r.frame_sparse_call(2.0 / tiles_n, 2.0 / tiles_n, view, origin, pkg.PACK_ROUND | pkg.ALPHA_COMPUTED)(buf.data_ptr(), st)
+            torch.cuda.synchronize()
+            sparse.append(buf)
+        out2 = torch.full((w * h,), 0x77, dtype=torch.int32, device="cuda")
+        r.scatter_sparse_device([b.data_ptr() for b in sparse], pkg.PACK_ROUND | pkg.ALPHA_COMPUTED, out2.data_ptr(), st)
+        torch.cuda.synchronize()
         r.set_shard(0, 1)
         ok_h = bool((img_h == img).all()); ok_s = bool((out.cpu().numpy().view(np.uint32).reshape(h, w) == img).all())
-        extra = f"  host tiles {'==' if ok_h else '!='}  shards x{world} {'==' if ok_s else '!='}"
-        if not (ok_h and ok_s):
+        ok_p = bool((out2.cpu().numpy().view(np.uint32).reshape(h, w) == img).all())
+        extra = f"  host tiles {'==' if ok_h else '!='}  shards x{world} {'==' if ok_s else '!='}  sparse shards {'==' if ok_p else '!='}"
+        if not (ok_h and ok_s and ok_p):
             errb = max(errb, 1.0)
     # (d) every fourth case: the point queries against the oracle (rt.h:32-54, 146-223; rt.cpp:8-27)
     if case % 4 == 1 and n <= 600:
