@@ -185,6 +185,30 @@ def test_transmittance_three_gaussians(pkg, oracle, renderer):
     renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
 
 
+def test_broadcast_transmittance_rays(pkg, oracle, renderer):
+    """vrt_hip_transmittance_rays == broadcast_transmittance (rt.h:102-127): every ray its own origin, direction and
+    sample point -- against the oracle's transmittance per ray, and equal to the one-ray entry point."""
+    g = oracle.gaussians([[0, 1, 0, .1], [0, 0, 1, .7], [1, 0, 0, 1]], [[.3, .3, .5], [-.3, -.3, 0], [0, 0, 2]],
+                         [.1, .4, .75], [2., .7, 1.])
+    rng = np.random.default_rng(11)
+    n = 130                                     # not a multiple of the wave size
+    origins = (rng.normal(size=(n, 3)) * 0.3 + np.array([0, 0, -5])).astype(np.float32)
+    d = rng.normal(size=(n, 3)) * 0.08 + np.array([0, 0, 1])
+    dirs = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    s = rng.uniform(-1.0, 9.0, n).astype(np.float32)        # incl. sample points behind the origin (T > 1, rt.h:121-126)
+    renderer.set_gaussians(g)
+    for ek, rk in [(pkg.EXP_VCL, pkg.ERF_AS), (pkg.EXP_LIBM, pkg.ERF_LIBM)]:
+        renderer.set_options(ek, rk, 1e-9)
+        T = renderer.transmittance_rays(origins, dirs, s)
+        To = np.array([oracle.transmittance(o, v, [sv], g, ek, rk)[0] for o, v, sv in zip(origins, dirs, s)], np.float32)
+        assert np.abs(T - To).max() <= 2e-6, (ek, rk)
+        for i in (0, 64, 129):
+            assert T[i] == renderer.transmittance(origins[i], dirs[i], s[i:i + 1])[0]
+    assert (To < 0.9).any() and (To > 0.99).any()          # the sample spans attenuated and free rays
+    assert renderer.transmittance_rays(origins[:0], dirs[:0], s[:0]).size == 0
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+
+
 def test_radiance_arbitrary_rays(pkg, oracle, renderer):
     """vrt_hip_radiance == radiance / broadcast_radiance (rt.h:146-223) incl. the w (alpha) component."""
     g = oracle.gaussians([[0, 1, 0, .1], [0, 0, 1, .7], [1, 0, 0, 1]], [[.3, .3, .5], [-.3, -.3, 0], [0, 0, 2]],
