@@ -1693,6 +1693,7 @@ __global__ __launch_bounds__(256) void scatter_sparse_kernel(ShardPtrs shards, u
 {
     const uint32_t *sh = shards.p[blockIdx.y];
     const uint32_t slot = blockIdx.x, n = sh[0], cap = sh[1];
+    if (cap != max_cells || sh[2] != cells_x * cells_y) return; // not a shard of this job's geometry: touch nothing
     if (slot >= n || slot >= max_cells) return;
     const uint32_t cpt = cells_x * cells_y;
     const uint32_t key = sh[SPARSE_HDR_WORDS + slot];
