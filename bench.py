@@ -125,6 +125,14 @@ def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
     sample_rays = ntiles * rows * tile_w
     terms_per_s = terms / dt
     frame_s = frame_terms / terms_per_s
+    # BASELINE configs[0] (`-g 4 -w 256 -q`, CPU SIMD path, single thread): the plumbing case, whole frame
+    g1 = scene_mod.grid_scene(4).view(O.GAUSSIAN)
+    cam1, _ = O.cli_camera(256, 256)
+    tiles1 = O.tile_gaussians(2.0 / 16, 2.0 / 16, g1, O.camera_view(cam1))
+    plane1 = O.camera_plane(cam1)
+    t1 = time.perf_counter()
+    _, terms1, _ = O.simd_render_tiled(256, 256, plane1, cam1.position[:], g1, tiles1, None, 1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": (w * h) / frame_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
         "busy_threads": cpu_s / dt, "terms_per_s_per_busy_thread": terms / max(cpu_s, 1e-9),
@@ -133,6 +141,8 @@ def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
                    f"({terms_per_s:.3e} terms/s, SIMD width {simd}); frame = {frame_terms:.3e} terms -> "
                    f"{frame_s:.1f} s/frame extrapolated by term count{budget_note}"),
         "ms_per_frame_extrapolated": frame_s * 1e3,
+        "cfg1_single_thread": {"workload": "-g 4 -w 256, 1 thread, whole frame", "ms_per_frame": dt1 * 1e3,
+                               "Mrays_per_s": 65536 / dt1 / 1e6, "terms_per_s": terms1 / dt1},
     }
 
 
