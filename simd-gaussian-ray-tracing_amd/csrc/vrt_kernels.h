@@ -111,7 +111,7 @@ struct RenderTarget {
     int sparse;
     uint32_t *keys, *sparse_hdr;
     uint32_t sparse_cap;      // capacity (cells) of the shard buffer: header word 1, locates the pixel region
-    unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=slow-path blocks
+    unsigned long long *stats; // nullable: [0]=block candidates [1]=tile entries [2]=dense blocks with more than DCAP survivors
                                // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
                                // [6]=dense blocks [7]=table blocks [8..11]=dense workgroup timeline [12]=sum over rays of (lane list length)^2
                                // [13..15]=dense kernel: (emitter chunk, absorber) visits evaluated in full / exactly zero / exactly -2A

@@ -47,6 +47,14 @@ def test_no_gpu_means_no_context(pkg):
     assert L.vrt_hip_create(0, C.byref(h)) == -3 and not h.value        # VRT_HIP_ERR_NO_DEVICE
     assert L.vrt_hip_create(0, None) == -1                                # VRT_HIP_ERR_INVALID
     assert L.vrt_hip_set_options(None, 1, 1, 0.0) == -1
+    # the multi-GPU group fails the same way, with a message, and the size queries of a missing context read 0
+    g = C.c_void_p()
+    dev = (C.c_int * 2)(0, 0)
+    assert L.vrt_hip_group_create(dev, 2, C.byref(g)) == -3 and not g.value
+    assert b"member 0" in L.vrt_hip_group_last_error(None)
+    assert L.vrt_hip_group_create(dev, 0, C.byref(g)) == -1
+    assert L.vrt_hip_group_size(None) == 0 and L.vrt_hip_group_ctx(None, 0) is None
+    assert L.vrt_hip_sparse_shard_words(None) == 0 and L.vrt_hip_image_pixels(None) == 0
 
 
 def test_host_scene_matches_oracle(pkg, oracle):
