@@ -273,6 +273,17 @@ class Renderer:
                 self._chk(rc, "frame_device")
         return call
 
+    def frame(self, tw, th, view, origin, pack, want_image=True, wait=True):
+        """vrt_hip_frame: tile_gaussians + render on the context's own stream and buffer (what the CLI calls)."""
+        v = np.ascontiguousarray(view, np.float32).ravel()
+        img = np.zeros(self.w * self.h, np.uint32) if want_image else None
+        self._chk(self._L.vrt_hip_frame(self._h, float(tw), float(th), _fp(v), _fp(_f3(origin)), int(pack),
+                                        img.ctypes.data if want_image else None, int(wait)), "frame")
+        return img.reshape(self.h, self.w) if want_image else None
+
+    def sync(self):
+        self._chk(self._L.vrt_hip_sync(self._h), "sync")
+
     def set_shard(self, rank, world):
         self._chk(self._L.vrt_hip_set_shard(self._h, rank, world), "set_shard")
 

@@ -94,6 +94,7 @@ struct vrt_hip_ctx {
     uint32_t frame_seq = 0, reset_seq = 0;
     int num_cus = 256;
     float table_hx = 0.f;  // vrt_hip_set_table_step(): 0 = the exact kernels only
+    int dense_idle_grid = 8; // workgroups of the dense launch when nothing is expected for it (VRT_HIP_DENSE_IDLE_GRID)
     int dense_waves = 16; // waves per block in the dense kernel (tuning knob: VRT_HIP_DENSE_WAVES = 4 | 8 | 16)
     bool work_is_ref = false; // render straight from the ref lists (no tile-level cull possible)
     bool lists_dirty = true;
@@ -515,7 +516,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     const TileLists geo = tile_geometry(c);
     if (geo.tile_w == 0 || geo.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "render: tile size is 0 pixels");
     const bool use_shard = c->world > 1 || shard_compact;
-    if (c->last_stream && c->last_stream != st && c->last_stream != c->stream) {
+    if (c->last_stream && c->last_stream != st) {
         // another stream than the last frame's: the list kernels of this frame rewrite lists and queue counters that
         // the previous frame's kernels may still be reading
         if (hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
@@ -601,7 +602,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (expect_dense) launch_order_dense(cg, st);
     {
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
-        if (!expect_dense) dense_grid = std::min(dense_grid, 8u);
+        if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)c->dense_idle_grid);
         if (c->table_hx > 0.f) {
             // opt-in table mode: the table kernel takes the whole dense queue and hands what it declines to a second
             // queue, which the exact kernel then works off (n_dense reads the always-zero word of the counter set)
@@ -678,6 +679,10 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     if (const char *e = getenv("VRT_HIP_RENDER_WAVES")) { // one-wave kernel: persistent waves per CU (tuning knob)
         const int v = atoi(e);
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
+    }
+    if (const char *e = getenv("VRT_HIP_DENSE_IDLE_GRID")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 256) c->dense_idle_grid = v;
     }
     if (const char *e = getenv("VRT_HIP_RENDER_NW")) {
         const int v = atoi(e);

@@ -622,6 +622,43 @@ def test_frames_enqueued_back_to_back_with_a_moving_camera(pkg, oracle, renderer
     assert dense_seen      # the orbit does pass through views that need the dense kernel
 
 
+def test_frames_on_the_context_stream_then_on_a_caller_stream(pkg, oracle, renderer):
+    """vrt_hip_frame without waiting (the CLI's animation loop: frames in flight on the context's own stream) followed at
+    once by a frame of another camera on a caller's stream: the library orders the two itself (lists and queue counters of
+    the first frame must not be rewritten under it)."""
+    import torch
+    from sgrt_amd import scene
+    w = h = 1024
+    g = oracle.grid_scene(64)
+    renderer.set_gaussians(g)
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    cam_a, cam_b = scene.cli_camera(w, h, initial_rot=50.0)[0], scene.cli_camera(w, h, initial_rot=0.0)[0]
+    side = torch.cuda.Stream()
+    out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        renderer.set_camera_view(w, h, cam_a.view)
+        for _k in range(3):
+            renderer.frame(2 / 16, 2 / 16, cam_a.view, cam_a.position, pack, want_image=False, wait=False)     # 50 degrees: heavy
+        renderer.set_camera_view(w, h, cam_b.view)
+        renderer.frame_call(2 / 16, 2 / 16, cam_b.view, cam_b.position, pack)(out.data_ptr(), side.cuda_stream)
+        renderer.set_camera_view(w, h, cam_a.view)
+        img_a = renderer.frame(2 / 16, 2 / 16, cam_a.view, cam_a.position, pack)                                   # waits
+        torch.cuda.synchronize()
+        got_b = out.cpu().numpy().view(np.uint32).reshape(h, w)
+        fresh = pkg.Renderer(0)
+        try:
+            fresh.set_gaussians(g)
+            for cam, got in ((cam_a, img_a), (cam_b, got_b)):
+                fresh.set_camera_view(w, h, cam.view)
+                fresh.tile_gaussians(2 / 16, 2 / 16, cam.view)
+                ref, _ = fresh.render(cam.position, pack, want_radiance=False)
+                np.testing.assert_array_equal(got, ref)
+        finally:
+            fresh.close()
+
+
 @pytest.mark.parametrize("name,step,rot", [("monkey", 0.12, 20.0), ("monkey", 0.12, 150.0), ("teapot", 0.2, 0.0)])
 def test_table_mode_stays_inside_the_tolerance(pkg, oracle, renderer, name, step, rot):
     """Opt-in table mode (vrt_hip_set_table_step): dense blocks interpolate the transmittance exponent from 160 nodes per
