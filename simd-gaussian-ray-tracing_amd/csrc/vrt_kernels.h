@@ -41,7 +41,16 @@ struct TileLists {
     uint32_t tiles_w, tiles_h;
     uint32_t tile_w, tile_h;  // pixels: (u64)(width*tw/2.f), rt.h:348-349
     uint32_t stride;          // tile_w * tiles_w: the reference's row stride, rt.h:364-365
+    // Per-tile slack of the cull threshold (nullable = 0 everywhere): cull_eps is calibrated for a tile list of CULL_REF_N
+    // Gaussians (the error of everything dropped along a ray is below ~3 * CULL_REF_N * cull_eps); a tile whose work list
+    // holds `n` candidates may drop candidates CULL_REF_N / n times larger for the same bound: x > cull_x - slack[t],
+    // slack[t] = ln(CULL_REF_N / n), written by the tile list kernel, applied by every cull below tile level.
+    // Thresholds at the Exp floor (`floor_x`: cull_eps = 0, or sigma*mag/cull_eps beyond it) mean "keep unless Exp gives
+    // exactly 0" and take no slack.
+    const float *slack;
+    float floor_x;
 };
+constexpr float CULL_REF_N = 4096.f;
 
 // Second-level (cell) candidate lists and the cell queues of the render kernels (empty cells: count == 0, no queue).
 struct CellGrid {
@@ -153,6 +162,8 @@ struct BinArgs {
     // output: list of tile t at out_indices[out_start[t] ...], length out_count[t]
     const uint32_t *out_start;
     uint32_t *out_indices, *out_count;
+    float *out_slack;                // nullable: per-tile threshold slack (TileLists::slack)
+    float floor_x;                   // TileLists::floor_x
     uint32_t *zero8;                 // nullable: 8 queue counters this launch clears for the kernels after it
     uint32_t *next_zero8;            // nullable: the OTHER counter set, cleared for the next list generation
 };

@@ -435,6 +435,11 @@ __device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/
     return !(xmin * 0.999f - 1e-3f > bq.w);
 }
 
+// cull_x of a candidate with the tile's slack applied (TileLists::slack).  A threshold at the Exp floor (cull_eps = 0 or a
+// huge sigma*mag) means "keep unless the contribution is exactly 0" and stays as it is; -inf (sigma*mag = 0) too.
+__device__ __forceinline__ float slack_cull_x(float cull_x, float slack, float floor_x) { return cull_x < floor_x ? cull_x - slack : cull_x; }
+__device__ __forceinline__ float tile_slack(const TileLists &T, uint32_t t) { return T.slack ? T.slack[t] : 0.f; }
+
 // ---------------------------------------------------------------------------------------------
 // Image kernel: persistent one-wave workgroups; a work item is one 8x8 pixel block (64 rays, lane = ray) of a
 // 32x32 pixel cell with a non-empty candidate list.  A wave's first block is static (item = wave); frames with
@@ -613,6 +618,7 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
         // ---- block cull over the cell's list (ballot compaction, order preserving; NW = 2: 128 entries per pass, the
         //      second wave's survivors behind the first's) ----
         __syncthreads(); // previous item's LDS reads are done
+        const float slack = tile_slack(T, p.t);
         uint32_t cnt = 0;
         for (uint32_t base = 0; base < n_list; base += 64 * NW) {
             const uint32_t k = base + wv * 64 + lane;
@@ -622,6 +628,7 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
             if (k < n_list) {
                 const uint32_t idx = list[k];
                 a = S.gA[idx]; bq = S.gB[idx]; ms = S.mu_sig[idx]; alb = S.gC[idx]; q = S.gD[idx].y;
+                bq.w = slack_cull_x(bq.w, slack, T.floor_x); // also what the per-ray cull below reads back from LDS
                 keep = cone_keeps(cone, a, bq);
             }
             const unsigned long long mask = __ballot(keep);
@@ -823,6 +830,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
             if (k < n_list) {
                 idx = list[k];
                 a = S.gA[idx]; bq = S.gB[idx];
+                bq.w = slack_cull_x(bq.w, tile_slack(T, p.t), T.floor_x);
                 keep = cone_keeps(cone, a, bq);
             }
             const unsigned long long mask = __ballot(keep);
@@ -1057,6 +1065,7 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
             if (k < n_list) {
                 idx = list[k];
                 a = S.gA[idx]; bq = S.gB[idx];
+                bq.w = slack_cull_x(bq.w, tile_slack(T, p.t), T.floor_x);
                 keep = cone_keeps(cone, a, bq);
             }
             const unsigned long long mask = __ballot(keep);
@@ -1461,7 +1470,12 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
         total += (uint32_t)__shfl((int)incl, 63, 64);
         __syncthreads();
     }
-    if (tid == 0) P.out_count[t] = total;
+    // the tile's threshold slack (TileLists::slack): from the size of its work list
+    const float slack = __logf(CULL_REF_N / (float)max(total, 1u));
+    if (tid == 0) {
+        P.out_count[t] = total;
+        if (P.out_slack) P.out_slack[t] = slack;
+    }
     if (tl) tl[2] = wall_clock64();
     if (!F.enabled) return;
 
@@ -1489,7 +1503,12 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
             uint32_t *cout = C.indices + (size_t)cell * C.cstride;
             for (uint32_t base = 0; base < total; base += 64) {
                 const uint32_t k = base + lane;
-                const bool keep = k < total && (!P.refine || cone_keeps(cc, s_A[k], s_B[k]));
+                bool keep = k < total;
+                if (keep && P.refine) {
+                    float4 bq = s_B[k];
+                    bq.w = slack_cull_x(bq.w, P.out_slack ? slack : 0.f, P.floor_x);
+                    keep = cone_keeps(cc, s_A[k], bq);
+                }
                 const unsigned long long mask = __ballot(keep);
                 const uint32_t pos = ctotal + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
                 if (keep && pos < C.cstride) cout[pos] = s_idx[k];
@@ -1615,7 +1634,13 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
                 uint32_t idx = 0;
                 if (k < n_in) {
                     idx = in_list[k];
-                    keep = refine ? cone_keeps(cone, S.gA[idx], S.gB[idx]) : true;
+                    if (refine) {
+                        float4 bq = S.gB[idx];
+                        bq.w = slack_cull_x(bq.w, tile_slack(T, t), T.floor_x);
+                        keep = cone_keeps(cone, S.gA[idx], bq);
+                    } else {
+                        keep = true;
+                    }
                 }
                 const unsigned long long mask = __ballot(keep);
                 const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));

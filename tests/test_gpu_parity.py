@@ -571,6 +571,41 @@ def test_work_queues_and_scheduling_do_not_change_the_image(pkg, oracle, rendere
         r1.close()
 
 
+@pytest.mark.parametrize("name,w,rot", [("g64", 1024, 47.0), ("teapot", 512, 0.0), ("monkey", 512, 20.0), ("cube", 256, 30.0)])
+def test_per_tile_cull_slack_keeps_the_error_bound(pkg, oracle, renderer, monkeypatch, name, w, rot):
+    """Below tile level the cull threshold of a tile with n candidates is cull_eps * 4096 / n (TileLists::slack): what is
+    dropped along a ray stays below ~3 * 4096 * cull_eps = 1.2e-5 whatever the scene.  Checked against the
+    full sum (cull_eps = 0) of the same context; the fixed threshold (VRT_HIP_ADAPTIVE_CULL=0) shades more entries for
+    less error, and both stay two orders of magnitude inside the parity tolerance of 1e-4."""
+    from sgrt_amd import scene
+    g = scene.grid_scene(64) if name == "g64" else scene.read_obj(os.path.join(GOLDEN, "test-objects", name + ".obj"))
+    cam, _ = scene.cli_camera(w, w, initial_rot=rot)
+
+    def frame(r, eps):
+        r.set_gaussians(g)
+        r.set_camera_view(w, w, cam.view)
+        r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps)
+        r.tile_gaussians(2 / 16, 2 / 16, cam.view)
+        r.enable_stats(True)
+        _, rad = r.render(cam.position)
+        st = r.stats()
+        r.enable_stats(False)
+        return rad.astype(np.float64), st["lane_entries"] + st["dense_visits_full"]
+
+    full, _ = frame(renderer, 0.0)
+    rad, work = frame(renderer, 1e-9)
+    monkeypatch.setenv("VRT_HIP_ADAPTIVE_CULL", "0")
+    r0 = pkg.Renderer(0)
+    try:
+        rad0, work0 = frame(r0, 1e-9)
+    finally:
+        r0.close()
+        renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    assert np.abs(rad - full).max() <= 1.3e-5
+    assert np.abs(rad0 - full).max() <= np.abs(rad - full).max() + 1e-6
+    assert work < work0
+
+
 def test_kernel_timing_modes(pkg, oracle, renderer):
     """vrt_hip_enable_kernel_timing: 1 = four events per frame, 2 = the one-wave kernel only, 3 = that on every 8th frame."""
     import torch
