@@ -76,8 +76,7 @@ struct vrt_hip_ctx {
     DevBuf<uint32_t> ref_start, ref_count, ref_indices;
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
-    DevBuf<float> w_slack;    // per-tile cull slack (TileLists::slack), written by the tile list kernel
-    bool adaptive_cull = true; // VRT_HIP_ADAPTIVE_CULL=0: the same threshold for every tile (round-1 behaviour)
+    float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
@@ -379,7 +378,6 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     HIPCHK(c, c->c_dense.reserve(c->n_cells));
     HIPCHK(c, c->c_dense_sorted.reserve(c->n_cells));
     HIPCHK(c, c->c_slot.reserve(c->n_cells));
-    HIPCHK(c, c->w_slack.reserve(nt));
     HIPCHK(c, c->c_scratch.reserve((size_t)c->num_cus * 4 * c->cstride)); // one slot per dense workgroup (<= 4 per CU)
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
     if (c->table_hx > 0.f) HIPCHK(c, c->c_overflow2.reserve((size_t)c->n_cells * 16));
@@ -392,6 +390,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
 
     BinArgs a = bin_args(c);
     a.refine = refine ? 1 : 0;
+    a.cull_ref_n = c->cull_ref_n; a.floor_x = exp_floor_x(c->exp_kind);
     a.R = ray_gen(c, origin);
     a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
     c->work_is_ref = false;
@@ -401,6 +400,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         c->last_stream = st;
         a = bin_args(c);
         a.refine = refine ? 1 : 0; a.R = ray_gen(c, origin);
+        a.cull_ref_n = c->cull_ref_n; a.floor_x = exp_floor_x(c->exp_kind);
         a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
     }
     const bool device_bin = c->tile_mode == TILES_DEVICE;
@@ -422,7 +422,6 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     a.zero8 = fuse ? nullptr : c->c_counters.p + 8 * (c->list_gen & 1);
     if (device_bin) {
         a.out_start = c->w_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
-        a.out_slack = c->adaptive_cull ? c->w_slack.p : nullptr; a.floor_x = exp_floor_x(c->exp_kind);
     } else if (refine) {
         const size_t total = c->tile_mode == TILES_NONE ? c->n : c->ref_indices.cap;
         HIPCHK(c, c->w_count.reserve(nt)); HIPCHK(c, c->w_indices.reserve(total));
@@ -430,7 +429,6 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         a.in_indices = c->tile_mode == TILES_NONE ? c->iota.p : c->ref_indices.p;
         a.tiles_w = geo.tiles_w;
         a.out_start = c->ref_start.p; a.out_indices = c->w_indices.p; a.out_count = c->w_count.p;
-        a.out_slack = c->adaptive_cull ? c->w_slack.p : nullptr; a.floor_x = exp_floor_x(c->exp_kind);
     } else {
         c->work_is_ref = true;
     }
@@ -465,7 +463,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
 TileLists work_lists(const vrt_hip_ctx *c)
 {
     TileLists t = tile_geometry(c);
-    t.slack = (c->adaptive_cull && !c->work_is_ref) ? c->w_slack.p : nullptr; // no tile kernel ran: nobody wrote a slack
+    t.cull_ref_n = c->cull_ref_n;
     t.floor_x = exp_floor_x(c->exp_kind);
     if (c->tile_mode == TILES_DEVICE) {
         t.start = c->w_start.p; t.count = c->w_count.p; t.indices = c->w_indices.p;
@@ -688,7 +686,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
         const int v = atoi(e);
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
     }
-    if (const char *e = getenv("VRT_HIP_ADAPTIVE_CULL")) c->adaptive_cull = atoi(e) != 0;
+    if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
     if (const char *e = getenv("VRT_HIP_DENSE_IDLE_GRID")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 256) c->dense_idle_grid = v;
@@ -719,7 +717,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     for (auto &b : c->soa) b.release();
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
-    c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->w_slack.release(); c->xc.release(); c->yc.release();
+    c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
     c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_overflow2.release(); c->c_counters.release(); c->c_rq.release(); c->c_slot.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();

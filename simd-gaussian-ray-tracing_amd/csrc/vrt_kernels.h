@@ -41,16 +41,17 @@ struct TileLists {
     uint32_t tiles_w, tiles_h;
     uint32_t tile_w, tile_h;  // pixels: (u64)(width*tw/2.f), rt.h:348-349
     uint32_t stride;          // tile_w * tiles_w: the reference's row stride, rt.h:364-365
-    // Per-tile slack of the cull threshold (nullable = 0 everywhere): cull_eps is calibrated for a tile list of CULL_REF_N
-    // Gaussians (the error of everything dropped along a ray is below ~3 * CULL_REF_N * cull_eps); a tile whose work list
-    // holds `n` candidates may drop candidates CULL_REF_N / n times larger for the same bound: x > cull_x - slack[t],
-    // slack[t] = ln(CULL_REF_N / n), written by the tile list kernel, applied by every cull below tile level.
-    // Thresholds at the Exp floor (`floor_x`: cull_eps = 0, or sigma*mag/cull_eps beyond it) mean "keep unless Exp gives
-    // exactly 0" and take no slack.
-    const float *slack;
+    // Level-wise cull thresholds (cull_ref_n = 0: one threshold everywhere).  cull_eps bounds what ONE dropped Gaussian
+    // could have contributed; what a ray loses is the sum over everything dropped on its way through the levels.  A level
+    // that `n` candidates enter (cell level: the tile's work list; block level: the cell's list; ray level: the block's
+    // survivors) drops a candidate when its best-case contribution is below cull_eps * cull_ref_n / n, so that the level as a
+    // whole loses less than ~3 * cull_ref_n * cull_eps whatever n is: short lists are cut harder, long lists more carefully
+    // than with one fixed threshold.  In the tables that is cull_x - ln(cull_ref_n / n).  Thresholds at the Exp floor
+    // (`floor_x`: cull_eps = 0, or sigma*mag/cull_eps beyond it) mean "keep unless Exp gives exactly 0" and stay.
+    float cull_ref_n;
     float floor_x;
 };
-constexpr float CULL_REF_N = 4096.f;
+
 
 // Second-level (cell) candidate lists and the cell queues of the render kernels (empty cells: count == 0, no queue).
 struct CellGrid {
@@ -162,8 +163,7 @@ struct BinArgs {
     // output: list of tile t at out_indices[out_start[t] ...], length out_count[t]
     const uint32_t *out_start;
     uint32_t *out_indices, *out_count;
-    float *out_slack;                // nullable: per-tile threshold slack (TileLists::slack)
-    float floor_x;                   // TileLists::floor_x
+    float cull_ref_n, floor_x;       // TileLists::cull_ref_n, floor_x
     uint32_t *zero8;                 // nullable: 8 queue counters this launch clears for the kernels after it
     uint32_t *next_zero8;            // nullable: the OTHER counter set, cleared for the next list generation
 };

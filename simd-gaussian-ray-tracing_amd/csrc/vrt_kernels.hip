@@ -435,10 +435,10 @@ __device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/
     return !(xmin * 0.999f - 1e-3f > bq.w);
 }
 
-// cull_x of a candidate with the tile's slack applied (TileLists::slack).  A threshold at the Exp floor (cull_eps = 0 or a
-// huge sigma*mag) means "keep unless the contribution is exactly 0" and stays as it is; -inf (sigma*mag = 0) too.
+// Level-wise thresholds (TileLists::cull_ref_n): the slack of a level that n candidates enter, and a candidate's cull_x with
+// it applied -- unless that sits at the Exp floor ("keep unless the contribution is exactly 0") or is -inf (sigma*mag = 0).
+__device__ __forceinline__ float level_slack(float cull_ref_n, uint32_t n) { return cull_ref_n > 0.f ? __logf(cull_ref_n / (float)max(n, 1u)) : 0.f; }
 __device__ __forceinline__ float slack_cull_x(float cull_x, float slack, float floor_x) { return cull_x < floor_x ? cull_x - slack : cull_x; }
-__device__ __forceinline__ float tile_slack(const TileLists &T, uint32_t t) { return T.slack ? T.slack[t] : 0.f; }
 
 // ---------------------------------------------------------------------------------------------
 // Image kernel: persistent one-wave workgroups; a work item is one 8x8 pixel block (64 rays, lane = ray) of a
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
         // ---- block cull over the cell's list (ballot compaction, order preserving; NW = 2: 128 entries per pass, the
         //      second wave's survivors behind the first's) ----
         __syncthreads(); // previous item's LDS reads are done
-        const float slack = tile_slack(T, p.t);
+        const float slack = level_slack(T.cull_ref_n, n_list);
         uint32_t cnt = 0;
         for (uint32_t base = 0; base < n_list; base += 64 * NW) {
             const uint32_t k = base + wv * 64 + lane;
@@ -628,8 +628,7 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
             if (k < n_list) {
                 const uint32_t idx = list[k];
                 a = S.gA[idx]; bq = S.gB[idx]; ms = S.mu_sig[idx]; alb = S.gC[idx]; q = S.gD[idx].y;
-                bq.w = slack_cull_x(bq.w, slack, T.floor_x); // also what the per-ray cull below reads back from LDS
-                keep = cone_keeps(cone, a, bq);
+                keep = cone_keeps(cone, a, make_float4(bq.x, bq.y, bq.z, slack_cull_x(bq.w, slack, T.floor_x)));
             }
             const unsigned long long mask = __ballot(keep);
             uint32_t before = 0, pass_total = (uint32_t)__popcll(mask);
@@ -652,11 +651,12 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
         uint32_t nl = 0;
         bool fast = cnt <= PCAP;
         if (fast) {
+            const float slack_r = level_slack(T.cull_ref_n, cnt); // ray level: the block's survivors enter
             for (uint32_t j = 0; j < cnt; ++j) {
                 const float4 a = s_A[j], bq = s_B[j];
                 const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
                 const float x = sub_ref(a.w, mul_ref(mubar, mubar)) * bq.y;
-                if (!(x > bq.w)) {
+                if (!(x > slack_cull_x(bq.w, slack_r, T.floor_x))) {
                     if (nl < PL && wv == 0) s_lane[nl * 64 + lane] = (uint8_t)j;
                     ++nl;
                 }
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
             if (k < n_list) {
                 idx = list[k];
                 a = S.gA[idx]; bq = S.gB[idx];
-                bq.w = slack_cull_x(bq.w, tile_slack(T, p.t), T.floor_x);
+                bq.w = slack_cull_x(bq.w, level_slack(T.cull_ref_n, n_list), T.floor_x);
                 keep = cone_keeps(cone, a, bq);
             }
             const unsigned long long mask = __ballot(keep);
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
             if (k < n_list) {
                 idx = list[k];
                 a = S.gA[idx]; bq = S.gB[idx];
-                bq.w = slack_cull_x(bq.w, tile_slack(T, p.t), T.floor_x);
+                bq.w = slack_cull_x(bq.w, level_slack(T.cull_ref_n, n_list), T.floor_x);
                 keep = cone_keeps(cone, a, bq);
             }
             const unsigned long long mask = __ballot(keep);
@@ -1470,12 +1470,8 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
         total += (uint32_t)__shfl((int)incl, 63, 64);
         __syncthreads();
     }
-    // the tile's threshold slack (TileLists::slack): from the size of its work list
-    const float slack = __logf(CULL_REF_N / (float)max(total, 1u));
-    if (tid == 0) {
-        P.out_count[t] = total;
-        if (P.out_slack) P.out_slack[t] = slack;
-    }
+    const float slack = level_slack(P.cull_ref_n, total); // cell level: the tile's work list enters
+    if (tid == 0) P.out_count[t] = total;
     if (tl) tl[2] = wall_clock64();
     if (!F.enabled) return;
 
@@ -1506,7 +1502,7 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
                 bool keep = k < total;
                 if (keep && P.refine) {
                     float4 bq = s_B[k];
-                    bq.w = slack_cull_x(bq.w, P.out_slack ? slack : 0.f, P.floor_x);
+                    bq.w = slack_cull_x(bq.w, slack, P.floor_x);
                     keep = cone_keeps(cc, s_A[k], bq);
                 }
                 const unsigned long long mask = __ballot(keep);
@@ -1636,7 +1632,7 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
                     idx = in_list[k];
                     if (refine) {
                         float4 bq = S.gB[idx];
-                        bq.w = slack_cull_x(bq.w, tile_slack(T, t), T.floor_x);
+                        bq.w = slack_cull_x(bq.w, level_slack(T.cull_ref_n, n_in), T.floor_x);
                         keep = cone_keeps(cone, S.gA[idx], bq);
                     } else {
                         keep = true;
