@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=16)
     ap.add_argument("--cull-eps", type=float, default=1e-9)
     ap.add_argument("--gather-frames", type=int, default=16, help="N > 1: frames per RCCL gather (one collective per batch)")
+    ap.add_argument("--no-batch", action="store_true", help="N > 1: launch every frame of a gather batch on its own (round-2 baseline)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial frames")
     ap.add_argument("--parallel", choices=["tiles", "frames"], default="tiles",
@@ -263,16 +264,49 @@ def main():
         def render_shard(b, f):
             sparse_frame(shard_ptr[b] + 4 * f * words, sp)
 
-        def assemble(b, f):
-            r.scatter_sparse_device([t_.data_ptr() for t_ in fg.gathered_shards(b, f)], pack, img_ptr, sp)
+        # The F frames of a gather batch go out as ONE launch of each kernel (vrt_hip_frame_batch_device: grid.y = frame;
+        # F contexts per buffer, every frame needs its own lists and queues), on a stream of their own per buffer: a rank
+        # that owns 1/N of the tiles has a few microseconds of work per frame -- launched frame by frame it is bound by
+        # launch latency (measured on one of 8 shards: 19 us per frame, against 2-4 us in batches of 16).
+        render_shard_batch = assemble_batch = None
+        if not args.no_batch:
+            # rank 0 assembles the F frames of a batch with one launch, each into a frame buffer of its own
+            images = images + [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(F - len(images))]
+            img_ptrs = [im.data_ptr() for im in images]
 
-    def run(nsteps, in_flight=nctx):
+            def assemble_batch(b, nf):
+                r.scatter_sparse_batch_device([fg.recv[b][q].data_ptr() for q in range(world)], fg.prefix[b], nf, pack, img_ptrs, sp,
+                                              retained=True)
+
+            groups = [[r] + [make_renderer() for _ in range(F - 1)], [make_renderer() for _ in range(F)]]
+            rstreams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            for gr in groups:
+                for r_ in gr[1:] if gr[0] is r else gr:
+                    r_.tile_gaussians_device(tw, th, view, sp)
+            torch.cuda.synchronize()
+            batch_calls = [gr[0].frame_batch_call(gr[1:], tw, th, [view] * F, [origin] * F, pack, out_kind=2) for gr in groups]
+            batch_ptrs = [[shard_ptr[b] + 4 * f * words for f in range(F)] for b in (0, 1)]
+            streams = streams + rstreams
+
+            def render_shard_batch(b, nf):
+                if fg.sent[b] is not None:
+                    rstreams[b].wait_event(fg.sent[b])     # the previous batch in this buffer has been copied out
+                batch_calls[b](batch_ptrs[b], rstreams[b].cuda_stream, nf)
+                done = torch.cuda.Event()
+                done.record(rstreams[b])
+                torch.cuda.current_stream().wait_event(done)
+
+        def assemble(b, f):
+            # `image` is written by nothing but this call: retained assembly (only cells that went dark are reset, not 16.8 MB)
+            r.scatter_sparse_device([t_.data_ptr() for t_ in fg.gathered_shards(b, f)], pack, img_ptr, sp, retained=True)
+
+    def run(nsteps, in_flight=nctx, serial=False):
         if solo:
             for k in range(nsteps):
                 i = k % in_flight
                 frames[i](img_ptrs[i], sps[i])
         else:
-            fg.run(nsteps, render_shard, assemble)
+            fg.run(nsteps, render_shard, assemble, *((render_shard_batch, assemble_batch) if not serial else ()))
 
     def barrier():
         # poll the streams' completion first: hipDeviceSynchronize alone wakes up ~0.1-0.2 ms after the GPU is done
@@ -289,7 +323,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(8)            # set-up, not warm-up: the dense-launch feedback of the library needs 8 frames of one scene to settle
+    # set-up, not warm-up: the dense-launch feedback of the library needs a few frames of one scene PER CONTEXT to settle
+    # (frame batches: every context renders one frame per batch, two groups of F contexts)
+    run(8 if (solo or args.no_batch) else 8 * F)
     run(args.warmup)
     barrier()
     # HIP events around the dominant kernel, on the stream it runs on, live in the timed region -- on every 8th frame:
@@ -301,21 +337,30 @@ def main():
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("VRT_BENCH_DEBUG") and not solo:
+        for b in (0, 1):
+            print(f"[debug rank {rank}] shard buffer {b} headers:", fg.shard[b].view(fg.F, fg.words)[:, :4].cpu().tolist(), "prefix", fg.prefix[b], file=sys.stderr)
+            if rank == 0 and fg.recv[b] is not None:
+                print(f"[debug rank {rank}] recv {b} headers:", fg.recv[b][:, :, :4].cpu().tolist(), file=sys.stderr)
+        if rank == 0:
+            print("[debug] lit pixels per image:", [int((im != 0).sum()) for im in images], file=sys.stderr)
     kt = r.kernel_timing()
     r.enable_kernel_timing(False)
     # after the timed region: strictly serial frames on one context (no events), then the per-kernel breakdown
     n_serial = min(args.steps, 400)
     barrier()
     t1 = time.perf_counter()
-    run(n_serial, 1)
+    run(n_serial, 1, serial=True)
     barrier()
     serial_ms = (time.perf_counter() - t1) / max(n_serial, 1) * 1e3
     r.enable_kernel_timing(1)
-    run(min(args.steps, 100), 1)
+    run(min(args.steps, 100), 1, serial=True)
     barrier()
     seq = r.kernel_timing()
     r.enable_kernel_timing(False)
     kt["lists_ms"], kt["dense_ms"], kt["render_serial_ms"] = seq["lists_ms"], seq["dense_ms"], seq["render_ms"]
+    if not kt["launches"] or not kt["render_ms"] > 0:   # frame batches carry no per-launch events: the serial launch's duration
+        kt["render_ms"] = seq["render_ms"]
 
     red_dev = "cuda" if backend == "nccl" else "cpu"
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -336,7 +381,11 @@ def main():
         r.set_shard(0, 1)
         _img, _ = r.render(origin, pack, want_radiance=False)
         # the gathered + assembled frame of the timed loop must be the single-GPU frame, bit for bit
-        frame_ok = all(bool((im.cpu().numpy().view(np.uint32) == _img.reshape(-1)).all()) for im in images)
+        bad = [(i_, int((im.cpu().numpy().view(np.uint32) != _img.reshape(-1)).sum())) for i_, im in enumerate(images)]
+        bad = [b_ for b_ in bad if b_[1]]
+        frame_ok = not bad
+        if bad:
+            print(f"bench.py: frame buffers that differ from the single-GPU frame (buffer, pixels): {bad}", file=sys.stderr)
         st = r.stats()
         r.enable_stats(False)
         r.set_shard(*((0, 1) if solo else (rank, world)))
@@ -409,9 +458,11 @@ def main():
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
                        "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
                        "parallelism": (f"whole frames on each of {world} ranks, no collective" if (solo and world > 1) else
-                                       f"tile-shard x{world}" + (f" + RCCL gather of sparse shards to rank 0 every {F} frames" if world > 1 else "")),
+                                       f"tile-shard x{world}" + (f" + RCCL gather of sparse shards to rank 0 every {F} frames" if world > 1 else "")
+                                       + (f", {F} frames per kernel launch" if (world > 1 and not args.no_batch) else "")),
                        "shard_transport": (None if solo else {"format": "sparse: 32x32-px cells that hold something", "bytes_per_frame":
-                                           fg.bytes_moved / max(1, fg.frames_moved), "compact_shards_would_be": (world - 1) * w * h * 4 // world}),
+                                           fg.bytes_moved / max(1, fg.frames_moved), "compact_shards_would_be": (world - 1) * w * h * 4 // world,
+                                           "batches_gathered_twice": fg.regathered}),
                        "frames_in_flight": nctx,
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

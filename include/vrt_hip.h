@@ -200,6 +200,33 @@ int vrt_hip_frame_sparse_device(vrt_hip_ctx *ctx, float tw, float th, const floa
                                 int pack_flags, uint32_t *d_sparse, void *hip_stream);
 int vrt_hip_scatter_sparse_device(vrt_hip_ctx *ctx, const uint32_t *const *d_shards, int nshards, int pack_flags,
                                   uint32_t *d_image, void *hip_stream);
+/* The same for a frame buffer that is reused frame after frame (the `image` of main.cpp:245, written every frame of the
+ * loop): by calling this variant the caller promises that d_image still holds what the previous call of this variant on
+ * this context left in it.  Then only the cells stored last time and not stored now are reset to background, instead
+ * of all w * h pixels (16.8 MB per 2048^2 frame) -- the same frame, bit for bit.  A new buffer, image size, tile grid
+ * or background falls back to the full fill by itself. */
+int vrt_hip_scatter_sparse_retained_device(vrt_hip_ctx *ctx, const uint32_t *const *d_shards, int nshards, int pack_flags,
+                                           uint32_t *d_image, void *hip_stream);
+/* Several frames per assembly (the other end of vrt_hip_frame_batch_device): frame f is assembled into d_images[f] -- all
+ * different buffers -- from shard s at d_shards[s] + f * frame_stride_words (what a gather of [rank][frame][prefix]
+ * delivers), with one launch for all frames; retained != 0 as in the retained variant, per buffer (the context keeps a
+ * history for up to 64 frame buffers). */
+int vrt_hip_scatter_sparse_batch_device(vrt_hip_ctx *ctx, const uint32_t *const *d_shards, int nshards,
+                                        size_t frame_stride_words, int nframes, int pack_flags, uint32_t *const *d_images,
+                                        int retained, void *hip_stream);
+
+/* Several frames per launch: the animation loop of main.cpp:257-335 (`--frames N`: the orbit's cameras are known in advance)
+ * with n frames handed over at once.  Frame i is rendered by ctxs[i] -- every frame needs a context of its own (lists,
+ * queues and per-origin tables are per frame; same scene, options, rays' image size, tile grid and shard in all of them) --
+ * with view matrix views[16 i ..] and origin origins[3 i ..] into d_out[i], exactly as vrt_hip_frame_device (out_kind 0),
+ * vrt_hip_frame_device(.., shard = 1) (out_kind 1) or vrt_hip_frame_sparse_device (out_kind 2) would, bit for bit; but
+ * each of the three kernels of a frame is launched ONCE for all n frames (grid.y = frame).  A sparse frame is tens of
+ * microseconds of dependent launches: a batch pays the launch gaps and the kernels' tails once, and a rank that owns an
+ * eighth of the tiles still fills its GPU.  Everything is enqueued on hip_stream; errors are reported through ctxs[0].
+ * Not batched (VRT_HIP_ERR_INVALID): table mode, tiles of more than 64 cells, plane arrays that are no pinhole bundle. */
+int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float th, const float *views,
+                               const float *origins, int pack_flags, uint32_t *const *d_out, int out_kind,
+                               void *hip_stream);
 
 /* -------- several GPUs from one process: replaces the thread pool over tiles (rt.h:355-399) one level up -------------
  * A group holds one context per entry of `devices` (a device may be listed more than once: each entry is a member

@@ -79,7 +79,10 @@ SYMBOLS = {
     "vrt_hip_image_pixels": (C.c_size_t, [_vp]),
     "vrt_hip_sparse_shard_words": (C.c_size_t, [_vp]),
     "vrt_hip_frame_sparse_device": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, _vp]),
+    "vrt_hip_frame_batch_device": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, C.c_int, _vp]),
     "vrt_hip_scatter_sparse_device": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int, _vp, _vp]),
+    "vrt_hip_scatter_sparse_retained_device": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int, _vp, _vp]),
+    "vrt_hip_scatter_sparse_batch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "vrt_hip_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     "vrt_hip_group_destroy": (None, [_vp]),
     "vrt_hip_group_size": (C.c_int, [_vp]),
@@ -311,11 +314,39 @@ class Renderer:
                 self._chk(rc, "frame_sparse_device")
         return call
 
-    def scatter_sparse_device(self, shard_ptrs, pack, d_image, stream=0):
-        """Background + every stored cell of every shard (device pointers readable from this context's GPU)."""
+    def frame_batch_call(self, others, tw, th, views, origins, pack, out_kind=0):
+        """Pre-marshalled vrt_hip_frame_batch_device: frame i of a batch is rendered by (self, *others)[i] with views[i],
+        origins[i]; returns f(out_ptrs, stream, n=None) -- the first n frames into the device pointers out_ptrs[i]
+        (out_kind 0: raster frames, 1: compact shards, 2: sparse shards), every kernel launched once for all of them."""
+        ctxs = [self, *others]
+        v = np.ascontiguousarray(views, np.float32).reshape(len(ctxs), 16).copy()
+        o = np.ascontiguousarray(origins, np.float32).reshape(len(ctxs), 3).copy()
+        harr = (_vp * len(ctxs))(*[c_._h.value for c_ in ctxs])
+        fn, vp, op = self._L.vrt_hip_frame_batch_device, _fp(v), _fp(o)
+        tw, th, pack, out_kind = float(tw), float(th), int(pack), int(out_kind)
+
+        def call(out_ptrs, stream=0, n=None, _keep=(v, o, ctxs)):
+            n = len(ctxs) if n is None else int(n)
+            outs = (_vp * n)(*[int(p_) for p_ in out_ptrs[:n]])
+            rc = fn(harr, n, tw, th, vp, op, pack, outs, out_kind, stream or None)
+            if rc != 0:
+                self._chk(rc, "frame_batch_device")
+        return call
+
+    def scatter_sparse_device(self, shard_ptrs, pack, d_image, stream=0, retained=False):
+        """Background + every stored cell of every shard (device pointers readable from this context's GPU).  retained:
+        d_image still holds this context's previous retained assembly -- only cells that went dark are reset."""
         arr = (_vp * len(shard_ptrs))(*[int(p) for p in shard_ptrs])
-        self._chk(self._L.vrt_hip_scatter_sparse_device(self._h, arr, len(shard_ptrs), int(pack), d_image, stream or None),
-                  "scatter_sparse_device")
+        fn = self._L.vrt_hip_scatter_sparse_retained_device if retained else self._L.vrt_hip_scatter_sparse_device
+        self._chk(fn(self._h, arr, len(shard_ptrs), int(pack), d_image, stream or None), "scatter_sparse_device")
+
+    def scatter_sparse_batch_device(self, shard_ptrs, frame_stride_words, nframes, pack, image_ptrs, stream=0, retained=False):
+        """vrt_hip_scatter_sparse_batch_device: frame f from shard s at shard_ptrs[s] + 4 * f * frame_stride_words bytes into
+        image_ptrs[f], all frames in one launch."""
+        arr = (_vp * len(shard_ptrs))(*[int(p) for p in shard_ptrs])
+        imgs = (_vp * nframes)(*[int(p) for p in image_ptrs[:nframes]])
+        self._chk(self._L.vrt_hip_scatter_sparse_batch_device(self._h, arr, len(shard_ptrs), int(frame_stride_words), int(nframes), int(pack),
+                                                              imgs, int(bool(retained)), stream or None), "scatter_sparse_batch_device")
 
     def assemble_shards_device(self, d_gathered, d_image, stream=0, rank_stride_px=None):
         """Scatter a rank-major gather result into raster order; rank_stride_px > shard_pixels() when the gather

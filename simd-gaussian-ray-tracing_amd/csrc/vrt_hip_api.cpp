@@ -76,6 +76,26 @@ struct vrt_hip_ctx {
     DevBuf<uint32_t> ref_start, ref_count, ref_indices;
     bool ref_valid = false;
     DevBuf<uint32_t> w_start, w_count, w_indices;
+    // frame batches (vrt_hip_frame_batch_device): while `defer` is set the three per-frame launches are recorded, not made
+    FrameArgs *defer = nullptr;
+    struct Deferred {
+        bool lists = false, from_list = false, render = false, order = false;
+        uint32_t list_grid = 0, render_grid = 0, dense_grid = 0;
+    } deferred;
+    // the context a batch is issued through keeps the argument rows: a ring of pinned host slots and device slots
+    static constexpr int BATCH_SLOTS = 4;
+    FrameArgs *batch_host = nullptr, *batch_dev = nullptr;
+    size_t batch_cap = 0; // frames per slot
+    hipEvent_t batch_copied[BATCH_SLOTS] = {};
+    uint32_t batch_seq = 0;
+    // retained assembly (vrt_hip_scatter_sparse_retained_device): which cells the buffer's last assembly stored
+    struct Retained {
+        uint32_t *image = nullptr;
+        uint64_t sig = 0;
+        uint32_t bg = 0, seq = 0;
+        DevBuf<uint32_t> stamp;
+    };
+    std::vector<Retained> retained; // one history per frame buffer (at most MAX_ASSEMBLY_FRAMES, oldest dropped)
     float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
@@ -434,7 +454,10 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     }
     if (fuse) {
         a.next_zero8 = other_set; // cleared for the next generation by workgroup 0
-        if (n_local) {
+        if (n_local && c->defer) {
+            c->defer->bin = a; c->defer->fuse = f;
+            c->deferred.lists = true; c->deferred.from_list = !device_bin; c->deferred.list_grid = n_local;
+        } else if (n_local) {
             launch_build_tile_lists(a, f, !device_bin, n_local, st);
         } else {
             // a rank that owns no tile (more ranks than tiles) launches no list kernel: nobody adds to this generation's
@@ -444,6 +467,8 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         }
         if (target) target->cleared = 1;
     } else {
+        if (c->defer) return fail(c, VRT_HIP_ERR_INVALID, "frame batch: tiles of more than 64 cells (or rays that are no pinhole bundle) "
+                                                          "need the two-kernel list path, which is not batched");
         if (!c->work_is_ref) launch_build_tile_lists(a, f, !device_bin, (uint32_t)nt, st);
         else HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1), 0, 8 * sizeof(uint32_t), st));
         HIPCHK(c, hipGetLastError());
@@ -476,8 +501,20 @@ TileLists work_lists(const vrt_hip_ctx *c)
     return t;
 }
 
-// owner of tile t: diagonal interleave, balanced for centred objects
-inline int shard_owner(uint32_t t, uint32_t tiles_w, int world) { return (int)((t + t / tiles_w) % (uint32_t)world); }
+// Owner of tile t = (tx, ty): the ranks form an a x b brick (a * b = world, a >= b as square as the divisors allow) that
+// tiles the tile grid, owner = tx % a + a * (ty % b).  Every a x b window of tiles holds every rank once, so an object that
+// covers a few tiles in the middle of the frame -- `-g 64 -w 2048` lights 4 x 4 of the 16 x 16 tiles -- is spread evenly:
+// the busiest of 8 ranks gets 14 % of its cells (ideal 12.5 %; dealing tiles along diagonals, as round 1 did, gave one
+// rank 25 %).  sharding.py mirrors this.
+inline int shard_owner(uint32_t t, uint32_t tiles_w, int world)
+{
+    uint32_t b = 1;
+    for (uint32_t d = 1; d * d <= (uint32_t)world; ++d)
+        if ((uint32_t)world % d == 0) b = d;
+    const uint32_t a = (uint32_t)world / b;
+    const uint32_t tx = t % tiles_w, ty = t / tiles_w;
+    return (int)(tx % a + a * (ty % b));
+}
 
 int rebuild_shard(vrt_hip_ctx *c)
 {
@@ -529,7 +566,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     }
     c->last_stream = st;
     hipEvent_t *tev = nullptr;
-    const bool timed_frame = c->timing_on && (c->timing_frame++ % c->timing_period) == 0;
+    const bool timed_frame = !c->defer && c->timing_on && (c->timing_frame++ % c->timing_period) == 0;
     if (timed_frame) {
         if (c->tev.empty()) {
             c->tev.resize(4 * vrt_hip_ctx::TIMING_RING);
@@ -601,6 +638,17 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (grid) ++c->rq_gen; // a skipped launch clears nothing: the sets must not swap
     cg.rq = c->c_rq.p + (c->rq_gen & 1) * RQ_N * RQ_STRIDE;
     cg.rq_next = c->c_rq.p + ((c->rq_gen + 1) & 1) * RQ_N * RQ_STRIDE;
+    if (c->defer) {
+        // a frame of a batch: the launches are made once for all frames by vrt_hip_frame_batch_device
+        if (c->table_hx > 0.f || c->render_nw != 1)
+            return fail(c, VRT_HIP_ERR_INVALID, "frame batch: table mode and two waves per block are not batched");
+        uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
+        if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)c->dense_idle_grid);
+        FrameArgs &fa = *c->defer;
+        fa.S = tables(c); fa.T = t; fa.C = cg; fa.R = ray_gen(c, origin); fa.O = o;
+        c->deferred.render = true; c->deferred.render_grid = grid; c->deferred.order = expect_dense; c->deferred.dense_grid = dense_grid;
+        return VRT_HIP_OK;
+    }
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
     launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->render_nw, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
@@ -722,6 +770,10 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
+    for (auto &r : c->retained) r.stamp.release();
+    if (c->batch_host) (void)hipHostFree(c->batch_host);
+    if (c->batch_dev) (void)hipFree(c->batch_dev);
+    for (auto &e : c->batch_copied) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->tev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1210,32 +1262,209 @@ int vrt_hip_frame_sparse_device(vrt_hip_ctx *c, float tw, float th, const float 
     return render_common(c, origin, pack_flags, d_sparse, nullptr, (hipStream_t)hip_stream, OUT_SPARSE);
 }
 
-int vrt_hip_scatter_sparse_device(vrt_hip_ctx *c, const uint32_t *const *d_shards, int nshards, int pack_flags, uint32_t *d_image,
-                                  void *hip_stream)
+int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float th, const float *views, const float *origins,
+                               int pack_flags, uint32_t *const *d_out, int out_kind, void *hip_stream)
 {
-    if (!c || !d_shards || !d_image || nshards < 1 || nshards > MAX_SHARDS) return VRT_HIP_ERR_INVALID;
+    if (!ctxs || n < 1 || !ctxs[0]) return VRT_HIP_ERR_INVALID;
+    vrt_hip_ctx *c0 = ctxs[0];
+    if (!views || !origins || !d_out) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: null argument");
+    if (n > 64) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: at most 64 frames per batch");
+    if (out_kind < OUT_RASTER || out_kind > OUT_SPARSE) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: out_kind is 0 (frame), 1 (compact shard) or 2 (sparse shard)");
+    hipStream_t st = (hipStream_t)hip_stream;
+    for (int i = 0; i < n; ++i) {
+        vrt_hip_ctx *c = ctxs[i];
+        if (!c || !d_out[i]) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: null context or output");
+        for (int k = 0; k < i; ++k)
+            if (ctxs[k] == c) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: a context holds ONE frame's lists and queues -- every frame of a batch needs its own");
+        if (c->device != c0->device || c->exp_kind != c0->exp_kind || c->erf_kind != c0->erf_kind || c->dense_waves != c0->dense_waves)
+            return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the contexts differ in device or in Exp / Erf / dense-kernel options");
+        if (c->w != c0->w || c->h != c0->h || c->n != c0->n || c->rank != c0->rank || c->world != c0->world)
+            return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the frames differ in image size, scene size or shard");
+        if (out_kind == OUT_SPARSE && (uintptr_t)d_out[i] % 16) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: sparse shard buffers must be 16-byte aligned");
+    }
+    HIPCHK(c0, hipSetDevice(c0->device));
+    // argument rows: slot (batch_seq % BATCH_SLOTS) of the pinned ring, copied to the same slot of the device ring
+    if ((size_t)n > c0->batch_cap) {
+        int rc = quiesce(c0);
+        if (rc) return rc;
+        HIPCHK(c0, hipStreamSynchronize(st));
+        if (c0->batch_host) (void)hipHostFree(c0->batch_host);
+        if (c0->batch_dev) (void)hipFree(c0->batch_dev);
+        c0->batch_host = c0->batch_dev = nullptr; c0->batch_cap = 0;
+        const size_t cap = std::max<size_t>(16, (size_t)n);
+        HIPCHK(c0, hipHostMalloc((void **)&c0->batch_host, cap * vrt_hip_ctx::BATCH_SLOTS * sizeof(FrameArgs), hipHostMallocDefault));
+        HIPCHK(c0, hipMalloc((void **)&c0->batch_dev, cap * vrt_hip_ctx::BATCH_SLOTS * sizeof(FrameArgs)));
+        c0->batch_cap = cap;
+        for (auto &e : c0->batch_copied) if (!e) HIPCHK(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const uint32_t slot = c0->batch_seq++ % vrt_hip_ctx::BATCH_SLOTS;
+    if (c0->batch_seq > (uint32_t)vrt_hip_ctx::BATCH_SLOTS) HIPCHK(c0, hipEventSynchronize(c0->batch_copied[slot])); // the copy that last read this slot
+    FrameArgs *rows = c0->batch_host + (size_t)slot * c0->batch_cap;
+    FrameArgs *d_rows = c0->batch_dev + (size_t)slot * c0->batch_cap;
+
+    // every frame's host work, memsets and per-origin table kernel as for a single frame; its three launches recorded
+    for (int i = 0; i < n; ++i) {
+        vrt_hip_ctx *c = ctxs[i];
+        c->defer = &rows[i];
+        c->deferred = vrt_hip_ctx::Deferred{};
+        int rc = vrt_hip_tile_gaussians_device(c, tw, th, views + 16 * (size_t)i, hip_stream);
+        if (!rc) rc = render_common(c, origins + 3 * (size_t)i, pack_flags, d_out[i], nullptr, st, out_kind);
+        c->defer = nullptr;
+        if (rc) {
+            if (c != c0) fail(c0, rc, std::string("frame_batch: frame ") + std::to_string(i) + ": " + c->err);
+            return rc;
+        }
+        const auto &d = c->deferred, &d0 = c0->deferred;
+        if (!d.render || d.lists != d0.lists || d.from_list != d0.from_list || d.list_grid != d0.list_grid || d.render_grid != d0.render_grid)
+            return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the frames differ in image size, tile grid, shard or scene size");
+    }
+    HIPCHK(c0, hipMemcpyAsync(d_rows, rows, (size_t)n * sizeof(FrameArgs), hipMemcpyHostToDevice, st));
+    HIPCHK(c0, hipEventRecord(c0->batch_copied[slot], st));
+    const auto &d0 = c0->deferred;
+    if (d0.lists) launch_build_tile_lists_batch(d_rows, (uint32_t)n, d0.from_list, d0.list_grid, st);
+    // one-wave kernel: the persistent grid of ONE frame fills the GPU; n frames share it (at least one workgroup each --
+    // a workgroup pulls the blocks beyond its first from the frame's queues)
+    static const uint32_t oversub = [] { const char *e = getenv("VRT_HIP_BATCH_OVERSUB"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
+    const uint32_t rgrid = d0.render_grid ? std::min(d0.render_grid, std::max(1u, (d0.render_grid * oversub + (uint32_t)n - 1) / (uint32_t)n)) : 0u;
+    launch_render_batch(d_rows, (uint32_t)n, rgrid, c0->exp_kind, c0->erf_kind, st);
+    uint32_t dgrid = 0;
+    for (int i = 0; i < n; ++i) {
+        if (ctxs[i]->deferred.order) launch_order_dense(rows[i].C, st);
+        dgrid = std::max(dgrid, ctxs[i]->deferred.dense_grid);
+    }
+    launch_render_dense_batch(d_rows, (uint32_t)n, dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
+    HIPCHK(c0, hipGetLastError());
+    return VRT_HIP_OK;
+}
+
+namespace {
+struct AssemblyGeometry {
+    TileLists t;
+    uint32_t cx, cy, max_cells, frame_cells, bg;
+    size_t npix, covered;
+    uint64_t sig;
+};
+int assembly_geometry(vrt_hip_ctx *c, int pack_flags, AssemblyGeometry &g)
+{
     int rc = check_ready(c);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    const TileLists t = tile_geometry(c);
-    if (t.tile_w == 0 || t.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse: tile size is 0 pixels");
+    g.t = tile_geometry(c);
+    if (g.t.tile_w == 0 || g.t.tile_h == 0) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse: tile size is 0 pixels");
+    g.bg = (pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u; // what the kernels write where nothing is lit
+    // the tiles cover the linear pixel range [0, stride * tile_h * tiles_h) (rt.h:364-365: pix = x + stride * y with the
+    // truncated tile size); what lies beyond is written by nobody in a single-GPU frame either and reads 0
+    g.npix = (size_t)c->w * c->h;
+    g.covered = std::min(g.npix, (size_t)g.t.stride * g.t.tile_h * g.t.tiles_h);
+    g.cx = (g.t.tile_w + CELL - 1) / CELL; g.cy = (g.t.tile_h + CELL - 1) / CELL;
+    // one workgroup per (shard, slot) up to the shard capacity -- the same on every rank of this context's job
+    g.max_cells = sparse_capacity(c);
+    g.frame_cells = g.t.tiles_w * g.t.tiles_h * g.cx * g.cy;
+    g.sig = ((uint64_t)g.t.tiles_w << 48) ^ ((uint64_t)g.t.tile_w << 32) ^ ((uint64_t)g.t.tile_h << 16) ^ g.t.tiles_h ^ ((uint64_t)c->w << 24) ^
+            ((uint64_t)c->h << 8);
+    return VRT_HIP_OK;
+}
+// Background of one frame buffer before its cells are scattered.  Retained: the caller promises that d_image still holds
+// what the previous retained assembly of this context left in it; then the 4 B per ray of background (16.8 MB per 2048^2
+// frame: ~4 us of HBM writes, more than a rank's share of the rendering at 8 GPUs) shrink to the cells that were lit last
+// time and are not now (clear_stale_cells_kernel, after the scatter).  A new buffer, image size, tile grid or background
+// value gets the full fill and starts a new history.
+int assembly_background(vrt_hip_ctx *c, const AssemblyGeometry &g, uint32_t *d_image, bool retained, hipStream_t st, uint32_t **stamp,
+                        uint32_t *seq, bool *incremental)
+{
+    *stamp = nullptr; *seq = 0; *incremental = false;
+    auto it = std::find_if(c->retained.begin(), c->retained.end(), [&](const vrt_hip_ctx::Retained &r) { return r.image == d_image; });
+    if (!retained) {
+        if (it != c->retained.end()) { // a plain assembly into a retained buffer ends its history
+            HIPCHK(c, hipStreamSynchronize(st));
+            it->stamp.release();
+            c->retained.erase(it);
+        }
+    } else {
+        if (it == c->retained.end()) {
+            if (c->retained.size() >= (size_t)MAX_ASSEMBLY_FRAMES) {
+                HIPCHK(c, hipStreamSynchronize(st));
+                c->retained.front().stamp.release();
+                c->retained.erase(c->retained.begin());
+            }
+            c->retained.emplace_back();
+            it = c->retained.end() - 1;
+            it->image = d_image;
+        }
+        *incremental = it->sig == g.sig && it->bg == g.bg && it->stamp.cap >= g.frame_cells && it->seq != 0 && it->seq != 0xFFFFFFFFu;
+        if (!*incremental) {
+            HIPCHK(c, it->stamp.reserve(g.frame_cells));
+            HIPCHK(c, hipMemsetAsync(it->stamp.p, 0, (size_t)g.frame_cells * sizeof(uint32_t), st));
+            it->sig = g.sig; it->bg = g.bg; it->seq = 0;
+        }
+        *seq = ++it->seq;
+        *stamp = it->stamp.p;
+    }
+    if (!*incremental) {
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)d_image, (int)g.bg, g.covered, st));
+        if (g.covered < g.npix) HIPCHK(c, hipMemsetAsync(d_image + g.covered, 0, (g.npix - g.covered) * sizeof(uint32_t), st));
+    }
+    return VRT_HIP_OK;
+}
+int scatter_sparse(vrt_hip_ctx *c, const uint32_t *const *d_shards, int nshards, int pack_flags, uint32_t *d_image, void *hip_stream,
+                   bool retained)
+{
+    if (!c || !d_shards || !d_image || nshards < 1 || nshards > MAX_SHARDS) return VRT_HIP_ERR_INVALID;
+    AssemblyGeometry g;
+    int rc = assembly_geometry(c, pack_flags, g);
+    if (rc) return rc;
     ShardPtrs sp{};
     for (int i = 0; i < nshards; ++i) {
         if (!d_shards[i]) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse: NULL shard");
         sp.p[i] = d_shards[i];
     }
     hipStream_t st = (hipStream_t)hip_stream;
-    const uint32_t bg = (pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u; // what the kernels write where nothing is lit
-    // the tiles cover the linear pixel range [0, stride * tile_h * tiles_h) (rt.h:364-365: pix = x + stride * y with the
-    // truncated tile size); what lies beyond is written by nobody in a single-GPU frame either and reads 0
-    const size_t npix = (size_t)c->w * c->h;
-    const size_t covered = std::min(npix, (size_t)t.stride * t.tile_h * t.tiles_h);
-    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)d_image, (int)bg, covered, st));
-    if (covered < npix) HIPCHK(c, hipMemsetAsync(d_image + covered, 0, (npix - covered) * sizeof(uint32_t), st));
-    const uint32_t cx = (t.tile_w + CELL - 1) / CELL, cy = (t.tile_h + CELL - 1) / CELL;
-    // one workgroup per (shard, slot) up to the shard capacity -- the same on every rank of this context's job
-    const uint32_t max_cells = sparse_capacity(c);
-    launch_scatter_sparse(sp, nshards, max_cells, d_image, t, cx, cy, c->w, c->h, st);
+    uint32_t *stamp, seq;
+    bool incremental;
+    if ((rc = assembly_background(c, g, d_image, retained, st, &stamp, &seq, &incremental))) return rc;
+    launch_scatter_sparse(sp, nshards, g.max_cells, d_image, g.t, g.cx, g.cy, c->w, c->h, stamp, seq, st);
+    if (incremental) launch_clear_stale_cells(stamp, seq, g.frame_cells, d_image, g.t, g.cx, g.cy, c->w, c->h, g.bg, st);
+    HIPCHK(c, hipGetLastError());
+    return VRT_HIP_OK;
+}
+} // namespace
+
+int vrt_hip_scatter_sparse_device(vrt_hip_ctx *c, const uint32_t *const *d_shards, int nshards, int pack_flags, uint32_t *d_image,
+                                  void *hip_stream)
+{
+    return scatter_sparse(c, d_shards, nshards, pack_flags, d_image, hip_stream, false);
+}
+int vrt_hip_scatter_sparse_retained_device(vrt_hip_ctx *c, const uint32_t *const *d_shards, int nshards, int pack_flags,
+                                           uint32_t *d_image, void *hip_stream)
+{
+    return scatter_sparse(c, d_shards, nshards, pack_flags, d_image, hip_stream, true);
+}
+int vrt_hip_scatter_sparse_batch_device(vrt_hip_ctx *c, const uint32_t *const *d_shards, int nshards, size_t frame_stride_words,
+                                        int nframes, int pack_flags, uint32_t *const *d_images, int retained, void *hip_stream)
+{
+    if (!c || !d_shards || !d_images || nshards < 1 || nshards > MAX_SHARDS) return VRT_HIP_ERR_INVALID;
+    if (nframes < 1 || nframes > MAX_ASSEMBLY_FRAMES) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse_batch: 1..64 frames per call");
+    if (frame_stride_words % 4) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse_batch: the frame stride must keep the shards 16-byte aligned");
+    AssemblyGeometry g;
+    int rc = assembly_geometry(c, pack_flags, g);
+    if (rc) return rc;
+    ShardPtrs sp{};
+    for (int i = 0; i < nshards; ++i) {
+        if (!d_shards[i]) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse_batch: NULL shard");
+        sp.p[i] = d_shards[i];
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    AssemblyFrames fr{};
+    for (int f = 0; f < nframes; ++f) {
+        if (!d_images[f]) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse_batch: NULL image");
+        for (int k = 0; k < f; ++k)
+            if (d_images[k] == d_images[f]) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse_batch: two frames of a batch into one buffer");
+        bool incremental;
+        if ((rc = assembly_background(c, g, d_images[f], retained != 0, st, &fr.stamp[f], &fr.seq[f], &incremental))) return rc;
+        fr.image[f] = d_images[f];
+        fr.clear[f] = incremental ? 1 : 0;
+    }
+    launch_assemble_sparse_batch(sp, nshards, frame_stride_words, fr, nframes, g.max_cells, g.frame_cells, g.t, g.cx, g.cy, c->w, c->h, g.bg, st);
     HIPCHK(c, hipGetLastError());
     return VRT_HIP_OK;
 }

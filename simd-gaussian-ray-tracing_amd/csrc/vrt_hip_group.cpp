@@ -192,7 +192,8 @@ int vrt_hip_group_frame(vrt_hip_group *g, float tw, float th, const float view[1
         GCHK(g, hipMalloc((void **)&g->image, npix * sizeof(uint32_t)));
         g->image_px = npix;
     }
-    const int rc = vrt_hip_scatter_sparse_device(root.ctx, ptrs.data(), n, pack_flags, g->image, root.stream);
+    // g->image is the group's own buffer and only this call writes it: the retained variant resets just the cells that went dark
+    const int rc = vrt_hip_scatter_sparse_retained_device(root.ctx, ptrs.data(), n, pack_flags, g->image, root.stream);
     if (rc != VRT_HIP_OK) return gfail(g, rc, std::string("group_frame: assemble: ") + vrt_hip_last_error(root.ctx));
     GCHK(g, hipEventRecord(g->assembled, root.stream));
     g->have_assembled = true;

@@ -177,6 +177,19 @@ struct FuseArgs {
     unsigned long long *timeline; // nullable diagnostics: 8 wall_clock64 stamps per tile workgroup
 };
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st);
+
+// Several frames per launch (vrt_hip_frame_batch_device): what one frame's three kernels take, as a row of a device array;
+// the batch variants of the kernels are the same code with blockIdx.y choosing the row.  A frame of a sparse scene is a
+// few tens of microseconds of dependent launches: n frames per launch pay the launch gaps and the tails once, and a rank
+// that owns an eighth of the tiles still fills its GPU.
+struct FrameArgs {
+    BinArgs bin; FuseArgs fuse;                                   // list kernel
+    SceneTables S; TileLists T; CellGrid C; RayGen R; RenderTarget O;   // one-wave kernel and dense kernel
+};
+void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, uint32_t ntiles, hipStream_t st);
+void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
+void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int dw, int exp_kind, int erf_kind,
+                               hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,
                      uint32_t world, uint64_t rank_stride, const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
 void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);
@@ -184,7 +197,22 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);
 constexpr int MAX_SHARDS = 64;
 struct ShardPtrs { const uint32_t *p[MAX_SHARDS]; };
 void launch_scatter_sparse(const ShardPtrs &shards, int nshards, uint32_t max_cells, uint32_t *image, const TileLists &t,
-                           uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, hipStream_t st);
+                           uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, uint32_t *stamp /* nullable */,
+                           uint32_t seq, hipStream_t st);
+// several frames per assembly launch: per frame its image, its stamps (nullable), its sequence number, and whether the
+// stale-cell pass applies (0: the buffer got the full background fill this time)
+constexpr int MAX_ASSEMBLY_FRAMES = 64;
+struct AssemblyFrames {
+    uint32_t *image[MAX_ASSEMBLY_FRAMES];
+    uint32_t *stamp[MAX_ASSEMBLY_FRAMES];
+    uint32_t seq[MAX_ASSEMBLY_FRAMES];
+    uint8_t clear[MAX_ASSEMBLY_FRAMES];
+};
+void launch_assemble_sparse_batch(const ShardPtrs &shards, int nshards, size_t frame_stride, const AssemblyFrames &frames, int nframes,
+                                  uint32_t max_cells, uint32_t n_cells, const TileLists &t, uint32_t cells_x, uint32_t cells_y,
+                                  uint32_t width, uint32_t height, uint32_t background, hipStream_t st);
+void launch_clear_stale_cells(const uint32_t *stamp, uint32_t seq, uint32_t n_cells, uint32_t *image, const TileLists &t,
+                              uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, uint32_t background, hipStream_t st);
 constexpr uint32_t SPARSE_HDR_WORDS = 4; // [0] cells stored, [1] capacity (cells), [2] cells per tile, [3] reserved
 __host__ __device__ inline size_t sparse_pixel_offset(uint32_t cap) { return (SPARSE_HDR_WORDS + (size_t)cap + 3) / 4 * 4; }
 

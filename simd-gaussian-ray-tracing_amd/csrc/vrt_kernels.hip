@@ -502,7 +502,7 @@ __device__ __forceinline__ void shade_range(const float4 *s_A, const float4 *s_B
 // (27 us against a balanced 21 us, VRT_HIP_TIMELINE); with half blocks pulled from the work queues the unit is half
 // as long and the per-SIMD sums even out.
 template <int EXP, int ERF, int EC, int NW>
-__global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+__device__ __forceinline__ void render_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R, const RenderTarget &O)
 {
     // every row a kept candidate needs later (absorber: A, B; emitter: mu/sigma, albedo, sigma*mag) is fetched in the one
     // round trip of the block cull: the shading loops then run out of LDS only
@@ -719,6 +719,19 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
     }
 }
 
+template <int EXP, int ERF, int EC, int NW>
+__global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+{
+    render_body<EXP, ERF, EC, NW>(S, T, C, R, O);
+}
+// several frames per launch: blockIdx.y is the frame (FrameArgs)
+template <int EXP, int ERF, int EC>
+__global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    render_body<EXP, ERF, EC, 1>(a.S, a.T, a.C, a.R, a.O);
+}
+
 // This file is compiled twice (csrc/Makefile): once for everything except the one-wave image kernel, and once with
 // -DVRT_TU_LANES for that kernel alone under -mllvm -amdgpu-sched-strategy=max-ilp.  The default scheduler chains the
 // 20 independent erf terms of an absorber one after the other through two registers to save VGPRs, so a wave that is
@@ -734,8 +747,8 @@ __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTa
 // from a queue with one atomic per block (a block is >= 1e5 instructions; the counter is cold).
 // ---------------------------------------------------------------------------------------------
 template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
-__global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
-                                                                RenderTarget O)
+__device__ __forceinline__ void render_dense_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R,
+                                                  const RenderTarget &O)
 {
     constexpr int DCAP = vrtk::DCAP;
     // One block of LDS carved by hand: the two rows the absorber loop reads sit in the first 64 KB, where a DS
@@ -977,6 +990,18 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S,
             if (O.radiance) O.radiance[out] = sum;
         }
     }
+}
+template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
+__global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
+                                                                RenderTarget O)
+{
+    render_dense_body<EXP, ERF, EC, DW, SKIP>(S, T, C, R, O);
+}
+template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
+__global__ __launch_bounds__(DW * 64, 4) void render_dense_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C, a.R, a.O);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1232,6 +1257,13 @@ static void launch_render_t(const SceneTables &s, const TileLists &t, const Cell
     else hipLaunchKernelGGL((render_kernel<EXP, ERF, 4, 1>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
 }
 
+template <int EXP, int ERF>
+static void launch_render_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, hipStream_t st)
+{
+    if (grid == 0 || nframes == 0) return;
+    hipLaunchKernelGGL((render_batch_kernel<EXP, ERF, 4>), dim3(grid, nframes), dim3(64), 0, st, d_frames);
+}
+
 #endif // VRT_TU_LANES
 
 #define VRT_DISPATCH_EXP_ERF(FN, ...)                                                              \
@@ -1254,6 +1286,10 @@ void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, 
 {
     VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, nw, st);
 }
+void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+{
+    VRT_DISPATCH_EXP_ERF(launch_render_batch_t, d_frames, nframes, grid, st);
+}
 #else
 
 template <int EXP, int ERF>
@@ -1270,6 +1306,21 @@ void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGri
                          const RenderTarget &o, uint32_t grid, int dw, int exp_kind, int erf_kind, hipStream_t st)
 {
     VRT_DISPATCH_EXP_ERF(launch_render_dense_t, s, t, c, r, o, grid, dw, st);
+}
+template <int EXP, int ERF>
+static void launch_render_dense_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int dw, hipStream_t st)
+{
+    if (grid == 0 || nframes == 0) return;
+    const dim3 g(grid, nframes);
+    if (dw == 17) hipLaunchKernelGGL((render_dense_batch_kernel<EXP, ERF, 6, 16, false>), g, dim3(1024), 0, st, d_frames);
+    else if (dw == 16) hipLaunchKernelGGL((render_dense_batch_kernel<EXP, ERF, 6, 16>), g, dim3(1024), 0, st, d_frames);
+    else if (dw == 8) hipLaunchKernelGGL((render_dense_batch_kernel<EXP, ERF, 6, 8>), g, dim3(512), 0, st, d_frames);
+    else hipLaunchKernelGGL((render_dense_batch_kernel<EXP, ERF, 6, 4>), g, dim3(256), 0, st, d_frames);
+}
+void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int dw, int exp_kind, int erf_kind,
+                               hipStream_t st)
+{
+    VRT_DISPATCH_EXP_ERF(launch_render_dense_batch_t, d_frames, nframes, grid, dw, st);
 }
 
 template <int EXP, int ERF>
@@ -1357,7 +1408,7 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st)
 // 32x32-pixel cells, files every non-empty cell as active or dense (at most two atomics per TILE) and clears the
 // pixels of empty cells on the spot -- no second kernel, no global round trip, no idle clear phase later.
 template <bool FROM_LIST>
-__global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseArgs F)
+__device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const FuseArgs &F)
 {
     __shared__ uint32_t s_wave_cnt[64];
     __shared__ uint32_t s_idx[TCAP];
@@ -1580,12 +1631,29 @@ __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseA
     }
     if (tl) tl[5] = wall_clock64();
 }
+template <bool FROM_LIST>
+__global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseArgs F)
+{
+    build_tile_lists_body<FROM_LIST>(P, F);
+}
+template <bool FROM_LIST>
+__global__ __launch_bounds__(1024) void build_tile_lists_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    build_tile_lists_body<FROM_LIST>(a.bin, a.fuse);
+}
 
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st)
 {
     if (!ntiles) return;
     if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, a, f);
     else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, a, f);
+}
+void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, uint32_t ntiles, hipStream_t st)
+{
+    if (!ntiles || !nframes) return;
+    if (from_list) hipLaunchKernelGGL(build_tile_lists_batch_kernel<true>, dim3(ntiles, nframes), dim3(1024), 0, st, d_frames);
+    else hipLaunchKernelGGL(build_tile_lists_batch_kernel<false>, dim3(ntiles, nframes), dim3(1024), 0, st, d_frames);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1709,10 +1777,12 @@ void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *
 
 // Frame assembly from sparse shards (multi-GPU): one workgroup per (shard, slot).  The shards may live in another
 // GPU's memory (peer access over xGMI): they are read once, 16 B per lane, and only the stored cells travel.
-__global__ __launch_bounds__(256) void scatter_sparse_kernel(ShardPtrs shards, uint32_t max_cells, uint32_t *image, TileLists T,
-                                                             uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height)
+// `stamp` (nullable): per cell of the FRAME (key order), the sequence number of the last assembly that stored it -- see
+// clear_stale_cells_kernel.
+__device__ __forceinline__ void scatter_sparse_body(const uint32_t *sh, uint32_t max_cells, uint32_t *image, const TileLists &T,
+                                                    uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height,
+                                                    uint32_t *stamp, uint32_t seq)
 {
-    const uint32_t *sh = shards.p[blockIdx.y];
     const uint32_t slot = blockIdx.x, n = sh[0], cap = sh[1];
     if (cap != max_cells || sh[2] != cells_x * cells_y) return; // not a shard of this job's geometry: touch nothing
     if (slot >= n || slot >= max_cells) return;
@@ -1721,6 +1791,7 @@ __global__ __launch_bounds__(256) void scatter_sparse_kernel(ShardPtrs shards, u
     const uint32_t t = key / cpt, ci = key % cpt;
     if (t >= T.tiles_w * T.tiles_h) return;
     const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+    if (stamp && threadIdx.x == 0) stamp[key] = seq;
     const uint4 *src = reinterpret_cast<const uint4 *>(sh + sparse_pixel_offset(cap) + (size_t)slot * (CELL * CELL));
     const uint64_t npix = (uint64_t)width * height;
     for (uint32_t q = threadIdx.x; q < CELL * CELL / 4; q += blockDim.x) { // one 4-pixel quad per lane and pass
@@ -1736,12 +1807,84 @@ __global__ __launch_bounds__(256) void scatter_sparse_kernel(ShardPtrs shards, u
     }
 }
 
+__global__ __launch_bounds__(256) void scatter_sparse_kernel(ShardPtrs shards, uint32_t max_cells, uint32_t *image, TileLists T,
+                                                             uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height,
+                                                             uint32_t *stamp, uint32_t seq)
+{
+    scatter_sparse_body(shards.p[blockIdx.y], max_cells, image, T, cells_x, cells_y, width, height, stamp, seq);
+}
+// several frames per launch (blockIdx.z): frame f's shard s starts frame_stride words behind frame f-1's
+__global__ __launch_bounds__(256) void scatter_sparse_batch_kernel(ShardPtrs shards, size_t frame_stride, AssemblyFrames F,
+                                                                   uint32_t max_cells, TileLists T, uint32_t cells_x, uint32_t cells_y,
+                                                                   uint32_t width, uint32_t height)
+{
+    const uint32_t f = blockIdx.z;
+    scatter_sparse_body(shards.p[blockIdx.y] + f * frame_stride, max_cells, F.image[f], T, cells_x, cells_y, width, height,
+                        F.stamp[f], F.seq[f]);
+}
+
+// Retained frames: an image buffer that still holds the previous assembly needs no background fill -- only the cells that
+// were stored last time and are not stored now go back to background.  One wave per cell of the frame: stamp == seq - 1
+// means "stored by the previous assembly, not by this one" (the scatter kernel of this assembly ran before this kernel).
+__device__ __forceinline__ void clear_stale_cells_body(const uint32_t *stamp, uint32_t seq, uint32_t n_cells, uint32_t *image,
+                                                       const TileLists &T, uint32_t cells_x, uint32_t cells_y, uint32_t width,
+                                                       uint32_t height, uint32_t background)
+{
+    const uint32_t key = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (!stamp || key >= n_cells || stamp[key] != seq - 1) return;
+    const uint32_t cpt = cells_x * cells_y;
+    const uint32_t t = key / cpt, ci = key % cpt;
+    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+    const uint64_t npix = (uint64_t)width * height;
+    for (uint32_t q = lane; q < CELL * CELL; q += 64) {
+        const uint32_t pxt = (ci % cells_x) * CELL + q % CELL, pyt = (ci / cells_x) * CELL + q / CELL;
+        const uint64_t pix = (uint64_t)(tx * T.tile_w + pxt) + (uint64_t)T.stride * (ty * T.tile_h + pyt);
+        if (pxt < T.tile_w && pyt < T.tile_h && pix < npix) image[pix] = background;
+    }
+}
+__global__ __launch_bounds__(256) void clear_stale_cells_kernel(const uint32_t *stamp, uint32_t seq, uint32_t n_cells, uint32_t *image,
+                                                                TileLists T, uint32_t cells_x, uint32_t cells_y, uint32_t width,
+                                                                uint32_t height, uint32_t background)
+{
+    clear_stale_cells_body(stamp, seq, n_cells, image, T, cells_x, cells_y, width, height, background);
+}
+// blockIdx.y = frame; frames whose buffer got the full fill this time carry clear[f] = 0
+__global__ __launch_bounds__(256) void clear_stale_cells_batch_kernel(AssemblyFrames F, uint32_t n_cells, TileLists T, uint32_t cells_x,
+                                                                      uint32_t cells_y, uint32_t width, uint32_t height,
+                                                                      uint32_t background)
+{
+    const uint32_t f = blockIdx.y;
+    if (!F.clear[f]) return;
+    clear_stale_cells_body(F.stamp[f], F.seq[f], n_cells, F.image[f], T, cells_x, cells_y, width, height, background);
+}
+
 void launch_scatter_sparse(const ShardPtrs &shards, int nshards, uint32_t max_cells, uint32_t *image, const TileLists &t,
-                           uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, hipStream_t st)
+                           uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, uint32_t *stamp, uint32_t seq,
+                           hipStream_t st)
 {
     if (nshards <= 0 || !max_cells) return;
     hipLaunchKernelGGL(scatter_sparse_kernel, dim3(max_cells, (uint32_t)nshards), dim3(256), 0, st, shards, max_cells, image, t,
-                       cells_x, cells_y, width, height);
+                       cells_x, cells_y, width, height, stamp, seq);
+}
+void launch_assemble_sparse_batch(const ShardPtrs &shards, int nshards, size_t frame_stride, const AssemblyFrames &frames, int nframes,
+                                  uint32_t max_cells, uint32_t n_cells, const TileLists &t, uint32_t cells_x, uint32_t cells_y,
+                                  uint32_t width, uint32_t height, uint32_t background, hipStream_t st)
+{
+    if (nshards <= 0 || nframes <= 0 || !max_cells) return;
+    hipLaunchKernelGGL(scatter_sparse_batch_kernel, dim3(max_cells, (uint32_t)nshards, (uint32_t)nframes), dim3(256), 0, st, shards,
+                       frame_stride, frames, max_cells, t, cells_x, cells_y, width, height);
+    bool any = false;
+    for (int f = 0; f < nframes; ++f) any = any || frames.clear[f];
+    if (any && n_cells)
+        hipLaunchKernelGGL(clear_stale_cells_batch_kernel, dim3((n_cells + 3) / 4, (uint32_t)nframes), dim3(256), 0, st, frames, n_cells, t,
+                           cells_x, cells_y, width, height, background);
+}
+void launch_clear_stale_cells(const uint32_t *stamp, uint32_t seq, uint32_t n_cells, uint32_t *image, const TileLists &t,
+                              uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, uint32_t background, hipStream_t st)
+{
+    if (!n_cells) return;
+    hipLaunchKernelGGL(clear_stale_cells_kernel, dim3((n_cells + 3) / 4), dim3(256), 0, st, stamp, seq, n_cells, image, t, cells_x,
+                       cells_y, width, height, background);
 }
 
 // ---------------------------------------------------------------------------------------------

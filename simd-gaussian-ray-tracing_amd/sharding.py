@@ -2,7 +2,8 @@
 and of the shard-buffer layout, plus the gather protocol bench.py runs over RCCL.
 
 A frame's reference tiles (tiles_w x tiles_h, row-major tile id t = ty*tiles_w + tx, rt.cpp:47-51) are
-dealt to ranks along diagonals: owner(t) = (t + t // tiles_w) % world.  Every rank renders its tiles
+dealt to ranks in a x b bricks (a * b = world, as square as the divisors allow): owner(tx, ty) = tx % a + a * (ty % b),
+so that every a x b window of tiles holds every rank once.  Every rank renders its tiles
 into a compact buffer [slot][tile_h][tile_w] (slots padded to the same count on every rank so that one
 fixed-size gather moves the frame); rank 0 scatters the rank-major concatenation into raster order --
 the copy loop of the reference's simd_render_image (rt.h:388-399).
@@ -14,7 +15,10 @@ SPARSE_HDR_WORDS = 4      # [0] cells stored, [1] capacity, [2] cells per tile, 
 
 
 def shard_owner(t, tiles_w, world):
-    return (t + t // tiles_w) % world
+    b = max(d for d in range(1, int(world ** 0.5) + 1) if world % d == 0)
+    a = world // b
+    ty, tx = divmod(t, tiles_w)
+    return tx % a + a * (ty % b)
 
 
 def shard_table(tiles_w, tiles_h, world):
@@ -206,9 +210,13 @@ def scatter_sparse(shards, tiles_w, tile_w, tile_h, height, width, background=0)
 
 
 class SparseFrameGatherer:
-    """FrameGatherer for sparse shards.  A shard's size is data (header word 0), a gather wants equal sizes: per batch the
-    ranks agree on the fullest shard of the batch (one tiny all-reduce(MAX) + one host read) and gather the prefix
-    [0, pixel offset + 1024 * that) of every frame's shard -- 0.8 MB instead of 16 MB per `-g 64 -w 2048` frame.
+    """FrameGatherer for sparse shards.  A shard's size is data (header word 0), a gather wants equal sizes: the ranks
+    gather the prefix [0, pixel offset + 1024 * cells) of every frame's shard, `cells` being the fullest shard any rank
+    has produced so far plus a quarter -- 0.8 MB instead of 16 MB per `-g 64 -w 2048` frame.  The first batch learns that
+    number with one tiny all-reduce(MAX) and a host read; later batches only CHECK it, one batch late and off the
+    critical path (the all-reduced maximum of a batch is copied to the host asynchronously and looked at when the batch
+    is finished: if a shard was fuller than the prefix that travelled, the batch is gathered again in full before it is
+    assembled) -- the frame loop never waits for the GPU.
 
     words    u32 per shard buffer (vrt_hip_sparse_shard_words(), the same on every rank); cap: its capacity in cells
     """
@@ -221,6 +229,12 @@ class SparseFrameGatherer:
         self.shard = [torch.zeros(self.F * self.words, dtype=torch.int32, device=device) for _ in range(2)]
         self.recv = [None, None]     # rank 0: [world, nf, prefix] of the batch in flight
         self.prefix = [0, 0]
+        self.sent = [None, None]     # CUDA event: the send copy of buffer b's last batch has been taken
+        self.cells_sent = [0, 0]     # cells of the prefix that travelled for the batch in buffer b
+        self.most = [None, None]     # pinned host copy of the batch's all-reduced fullest shard (None: known, fits)
+        self.most_ready = [None, None]
+        self.cells_hint = None       # fullest shard seen so far (all ranks agree: it is all-reduced)
+        self.regathered = 0
         self.bytes_moved = 0
         self.frames_moved = 0
 
@@ -231,16 +245,15 @@ class SparseFrameGatherer:
         """Rank 0: the `world` shard prefixes of frame f of buffer b (tensor views, one per rank)."""
         return [self.recv[b][q, f] for q in range(self.world)]
 
-    def start(self, b, nf):
+    def _gather(self, b, nf, cells):
         import torch
         frames = self.shard[b].view(self.F, self.words)[:nf]
-        most = frames[:, 0].max().reshape(1).to(torch.int64)          # cells of the fullest shard of this batch, this rank
-        if self.stage:
-            most = most.cpu()
-        self.dist.all_reduce(most, op=self.dist.ReduceOp.MAX)
-        prefix = self.P + int(most.item()) * CELL * CELL                # host read: the one synchronisation per batch
+        prefix = self.P + int(cells) * CELL * CELL
         send = frames[:, :prefix].contiguous()
-        self.prefix[b] = prefix
+        if send.is_cuda:                                               # the shard buffer may be rendered into again after this
+            self.sent[b] = torch.cuda.Event()
+            self.sent[b].record()
+        self.prefix[b], self.cells_sent[b] = prefix, int(cells)
         if self.rank == 0:
             self.recv[b] = torch.empty((self.world, nf, prefix), dtype=torch.int32, device=self.device)
             self.bytes_moved += (self.world - 1) * nf * prefix * 4
@@ -256,16 +269,55 @@ class SparseFrameGatherer:
                 dst[q].copy_(out[q])
         return None
 
-    def run(self, nsteps, render, assemble):
-        """nsteps frames: render(b, f) fills shard_frame(b, f); assemble(b, f) is called on rank 0 for every gathered frame."""
+    def start(self, b, nf):
+        import torch
+        frames = self.shard[b].view(self.F, self.words)[:nf]
+        most = frames[:, 0].max().reshape(1).to(torch.int64)          # cells of the fullest shard of this batch, this rank
+        if self.stage:
+            most = most.cpu()
+        self.dist.all_reduce(most, op=self.dist.ReduceOp.MAX)
+        self.most[b] = self.most_ready[b] = None
+        if self.cells_hint is None or self.stage:
+            self.cells_hint = max(self.cells_hint or 0, int(most.item()))   # first batch (and the CPU-staged path): host read
+            cells = self.cells_hint
+        else:
+            cells = min(self.cap, self.cells_hint + self.cells_hint // 4 + 8)
+            if most.is_cuda:
+                host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                host.copy_(most, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            else:                                                       # CPU tensors (the gloo tests): nothing to wait for
+                host, ev = most.clone(), None
+            self.most[b], self.most_ready[b] = host, ev
+        return self._gather(b, nf, cells)
+
+    def run(self, nsteps, render, assemble, render_batch=None, assemble_batch=None):
+        """nsteps frames: render(b, f) fills shard_frame(b, f) -- or render_batch(b, nf) the first nf frames of buffer b at
+        once; assemble(b, f) is called on rank 0 for every gathered frame -- or assemble_batch(b, nf) once per batch (frame
+        f's shard of rank q is recv[b][q, f]: base recv[b][q], frame stride prefix[b] words)."""
         pending, nfs, busy = [None, None], [0, 0], [False, False]
 
         def finish(b):
             if pending[b] is not None:
                 pending[b].wait()
+            if self.most[b] is not None:                              # the deferred check of this batch's prefix
+                if self.most_ready[b] is not None:
+                    self.most_ready[b].synchronize()
+                most = int(self.most[b].item())
+                self.most[b] = None
+                self.cells_hint = max(self.cells_hint, most)
+                if most > self.cells_sent[b]:                         # a shard was fuller than what travelled: once more, in full
+                    self.regathered += 1
+                    again = self._gather(b, nfs[b], most)
+                    if again is not None:
+                        again.wait()
             if self.rank == 0:
-                for f in range(nfs[b]):
-                    assemble(b, f)
+                if assemble_batch is not None:
+                    assemble_batch(b, nfs[b])
+                else:
+                    for f in range(nfs[b]):
+                        assemble(b, f)
             pending[b], busy[b] = None, False
 
         F = self.F
@@ -273,8 +325,11 @@ class SparseFrameGatherer:
             b, nf = i & 1, min(F, nsteps - i * F)
             if busy[b]:
                 finish(b)
-            for f in range(nf):
-                render(b, f)
+            if render_batch is not None:
+                render_batch(b, nf)
+            else:
+                for f in range(nf):
+                    render(b, f)
             nfs[b], pending[b], busy[b] = nf, self.start(b, nf), True
             if busy[1 - b]:
                 finish(1 - b)

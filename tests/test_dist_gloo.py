@@ -125,7 +125,7 @@ def test_batched_frame_loop(world, nsteps, frames_per_gather, tmp_path, pkg):
     assert int(np.load(out)[0]) == nsteps
 
 
-def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather):
+def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather, grow=False):
     """The sparse protocol (sharding.SparseFrameGatherer, what bench.py runs over RCCL for N > 1) on CPU tensors: frames
     whose lit cells move from frame to frame, tiles that are not a multiple of the 32-px cell, more ranks than lit tiles."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -144,7 +144,8 @@ def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather):
 
         def frame_image(k):                            # a blob that moves with k over a zero background
             yy, xx = np.mgrid[0:h, 0:w]
-            blob = ((yy - (20 + 9 * k) % h) ** 2 + (xx - (30 + 31 * k) % w) ** 2) < (18 + 3 * (k % 4)) ** 2
+            radius = (6 + 22 * (k // frames_per_gather)) if grow else (18 + 3 * (k % 4))   # grow: every batch fuller than the prefix
+            blob = ((yy - (20 + 9 * k) % h) ** 2 + (xx - (30 + 31 * k) % w) ** 2) < radius ** 2
             return np.where(blob, (np.uint32(0x01000000) + (yy * w + xx + k).astype(np.uint32)), np.uint32(0)).astype(np.uint32)
 
         fg = sharding.SparseFrameGatherer(dist, rank, world, words, cap, frames_per_gather, "cpu")
@@ -166,19 +167,22 @@ def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather):
             for k, fr in frames:
                 np.testing.assert_array_equal(fr, frame_image(k))
             dense_bytes = (world - 1) * nsteps * tab.shape[1] * tile_w * tile_h * 4
-            np.save(out_path, np.array([len(frames), fg.bytes_moved, dense_bytes]))
+            np.save(out_path, np.array([len(frames), fg.bytes_moved, dense_bytes, fg.regathered]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nsteps,frames_per_gather", [(2, 7, 3), (3, 5, 2), (8, 4, 4)])
-def test_sparse_shard_frame_loop(world, nsteps, frames_per_gather, tmp_path, pkg):
+@pytest.mark.parametrize("world,nsteps,frames_per_gather,grow", [(2, 7, 3, False), (3, 5, 2, False), (8, 4, 4, False), (2, 8, 2, True)])
+def test_sparse_shard_frame_loop(world, nsteps, frames_per_gather, grow, tmp_path, pkg):
+    """grow: the lit area grows from batch to batch faster than the margin on the travelling prefix -- the check that runs
+    one batch late must notice and gather those batches again in full before they are assembled."""
     out = str(tmp_path / "n.npy")
-    mp.spawn(_sparse_loop_worker, args=(world, _free_port(), out, nsteps, frames_per_gather), nprocs=world, join=True)
-    n, moved, dense = np.load(out)
+    mp.spawn(_sparse_loop_worker, args=(world, _free_port(), out, nsteps, frames_per_gather, grow), nprocs=world, join=True)
+    n, moved, dense, regathered = np.load(out)
     assert int(n) == nsteps
-    assert moved < dense            # fewer bytes travel than the compact shards would take
+    assert moved < dense or grow    # fewer bytes travel than the compact shards would take
+    assert (regathered > 0) == grow
 
 
 def test_sparse_shard_layout_round_trip(pkg):

@@ -1,0 +1,166 @@
+"""GPU tests of frame batches (vrt_hip_frame_batch_device): n frames, n contexts, every kernel launched once with the
+frame as grid.y -- the result of each frame must be what vrt_hip_frame_device / vrt_hip_frame_sparse_device gives for it
+alone, bit for bit: moving cameras, sparse and dense scenes, raster frames, compact and sparse shards, batches back to
+back (the argument ring, the counter generations), a shorter batch after a longer one; and the refusals."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+OBJ = os.path.join(GOLDEN, "test-objects")
+
+
+def make_contexts(pkg, n, g, w, h, cam0, shard=(0, 1)):
+    ctxs = []
+    for _ in range(n):
+        r = pkg.Renderer(0)
+        r.set_gaussians(g)
+        r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+        r.set_camera_view(w, h, cam0.view)
+        r.set_shard(*shard)
+        ctxs.append(r)
+    return ctxs
+
+
+@pytest.mark.parametrize("name,w,h,tiles_n,n", [("g64", 768, 768, 16, 5), ("g16", 512, 384, 8, 16), ("monkey", 256, 256, 8, 3),
+                                                 ("cube", 200, 136, 5, 4)])
+def test_batch_equals_single_frames(pkg, renderer, name, w, h, tiles_n, n):
+    import torch
+    from sgrt_amd import scene
+    g = {"g64": lambda: scene.grid_scene(64), "g16": lambda: scene.grid_scene(16),
+         "monkey": lambda: scene.read_obj(os.path.join(OBJ, "monkey.obj")),
+         "cube": lambda: scene.read_obj(os.path.join(OBJ, "cube.obj"))}[name]()
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    cams = [scene.cli_camera(w, h, initial_rot=7.0 * i)[0] for i in range(2 * n)]
+    tw = th = 2.0 / tiles_n
+    # reference: every frame on its own, one context
+    renderer.set_gaussians(g)
+    renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    renderer.set_table_step(0.0)
+    renderer.set_shard(0, 1)
+    want = []
+    for c in cams:
+        renderer.set_camera_view(w, h, c.view)
+        renderer.tile_gaussians(tw, th, c.view)
+        want.append(renderer.render(c.position, pack, want_radiance=False)[0].reshape(-1))
+    st = torch.cuda.current_stream().cuda_stream
+    ctxs = make_contexts(pkg, n, g, w, h, cams[0])
+    try:
+        # (pixels no tile covers -- 136 rows in 5 tiles of 27 -- are never written: 0 as in vrt_hip_frame's own buffer)
+        fill = 0 if name == "cube" else 0x55
+        outs = [torch.full((w * h,), fill, dtype=torch.int32, device="cuda") for _ in range(n)]
+        ptrs = [o.data_ptr() for o in outs]
+        for half in range(2):                       # two batches back to back, other cameras in the second
+            cs = cams[half * n:(half + 1) * n]
+            for r, c in zip(ctxs, cs):
+                r.set_camera_view(w, h, c.view)
+            f = ctxs[0].frame_batch_call(ctxs[1:], tw, th, [c.view for c in cs], [c.position for c in cs], pack)
+            f(ptrs, st)
+            if half == 0:
+                f(ptrs, st)                         # the same batch again right behind (argument ring, counter generations)
+            torch.cuda.synchronize()
+            for i in range(n):
+                np.testing.assert_array_equal(outs[i].cpu().numpy().view(np.uint32), want[half * n + i], err_msg=f"batch {half} frame {i}")
+        # a shorter batch through the same contexts
+        m = max(1, n // 2)
+        for o in outs:
+            o.fill_(0 if name == "cube" else 0x33)
+        f = ctxs[0].frame_batch_call(ctxs[1:m], tw, th, [c.view for c in cams[n:n + m]], [c.position for c in cams[n:n + m]], pack)
+        f(ptrs, st)
+        torch.cuda.synchronize()
+        for i in range(m):
+            np.testing.assert_array_equal(outs[i].cpu().numpy().view(np.uint32), want[n + i])
+    finally:
+        for r in ctxs:
+            r.close()
+
+
+@pytest.mark.parametrize("name,w,tiles_n,world,rank", [("g64", 1024, 16, 8, 3), ("monkey", 256, 8, 3, 1), ("g4", 96, 2, 8, 7)])
+def test_batch_of_sparse_shards(pkg, renderer, name, w, tiles_n, world, rank):
+    """out_kind 2: the shard of rank `rank` for n frames in one batch == vrt_hip_frame_sparse_device frame by frame
+    (header, keys and the pixels of every stored cell)."""
+    import torch
+    from sgrt_amd import scene
+    g = {"g64": lambda: scene.grid_scene(64), "g4": lambda: scene.grid_scene(4),
+         "monkey": lambda: scene.read_obj(os.path.join(OBJ, "monkey.obj"))}[name]()
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    n = 4
+    cams = [scene.cli_camera(w, w, initial_rot=11.0 * i)[0] for i in range(n)]
+    tw = th = 2.0 / tiles_n
+    st = torch.cuda.current_stream().cuda_stream
+    ctxs = make_contexts(pkg, n + 1, g, w, w, cams[0], shard=(rank, world))
+    try:
+        single = ctxs[n]
+        single.tile_gaussians_device(tw, th, cams[0].view, st)
+        words = single.sparse_shard_words()
+        want = []
+        for c in cams:
+            single.set_camera_view(w, w, c.view)
+            buf = torch.zeros(words, dtype=torch.int32, device="cuda")
+            single.frame_sparse_call(tw, th, c.view, c.position, pack)(buf.data_ptr(), st)
+            torch.cuda.synchronize()
+            want.append(buf.cpu().numpy().view(np.uint32))
+        for r, c in zip(ctxs[:n], cams):
+            r.set_camera_view(w, w, c.view)
+            r.tile_gaussians_device(tw, th, c.view, st)
+        bufs = [torch.zeros(words, dtype=torch.int32, device="cuda") for _ in range(n)]
+        f = ctxs[0].frame_batch_call(ctxs[1:n], tw, th, [c.view for c in cams], [c.position for c in cams], pack, out_kind=2)
+        f([b.data_ptr() for b in bufs], st)
+        torch.cuda.synchronize()
+        stored = 0
+        for i in range(n):
+            got = bufs[i].cpu().numpy().view(np.uint32)
+            cells, cap = int(want[i][0]), int(want[i][1])
+            np.testing.assert_array_equal(got[:4], want[i][:4])
+            off = (4 + cap + 3) // 4 * 4
+            # which slot a cell gets is decided by the order in which tiles file their cells (atomics): compare by key
+            def by_key(buf):
+                order = np.argsort(buf[4:4 + cells], kind="stable")
+                return buf[4:4 + cells][order], buf[off:off + 1024 * cells].reshape(cells, 1024)[order]
+            gk, gp = by_key(got)
+            wk, wp = by_key(want[i])
+            np.testing.assert_array_equal(gk, wk)
+            np.testing.assert_array_equal(gp, wp)
+            stored += cells
+        assert stored > 0 or name == "g4"                  # g4: rank 7 of 8 owns none of the four tiles
+    finally:
+        for r in ctxs:
+            r.close()
+
+
+def test_batch_refusals(pkg, renderer):
+    import torch
+    from sgrt_amd import scene
+    g = scene.grid_scene(8)
+    w = 128
+    cam, _ = scene.cli_camera(w, w)
+    ctxs = make_contexts(pkg, 2, g, w, w, cam)
+    out = [torch.zeros(w * w, dtype=torch.int32, device="cuda") for _ in range(2)]
+    ptrs = [o.data_ptr() for o in out]
+    try:
+        with pytest.raises(pkg.VrtHipError, match="own"):     # one context cannot hold two frames
+            ctxs[0].frame_batch_call([ctxs[0]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
+        ctxs[1].set_options(pkg.EXP_LIBM, pkg.ERF_LIBM, 1e-9)
+        with pytest.raises(pkg.VrtHipError, match="differ"):
+            ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
+        ctxs[1].set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+        ctxs[1].set_camera_view(64, 64, cam.view)
+        with pytest.raises(pkg.VrtHipError, match="differ"):
+            ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
+        ctxs[1].set_camera_view(w, w, cam.view)
+        for r in ctxs:
+            r.set_table_step(0.1)
+        with pytest.raises(pkg.VrtHipError, match="table"):
+            ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
+        for r in ctxs:
+            r.set_table_step(0.0)
+        # and it still works afterwards
+        ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
+        torch.cuda.synchronize()
+        assert (out[0] == out[1]).all() and int((out[0] != 0).sum()) > 0
+    finally:
+        for r in ctxs:
+            r.close()

@@ -91,6 +91,103 @@ def test_sparse_shards_assemble_to_the_single_gpu_frame(pkg, renderer, scene_nam
             r.close()
 
 
+def test_retained_assembly_equals_full_assembly(pkg, renderer):
+    """vrt_hip_scatter_sparse_retained_device: a frame buffer that keeps the previous assembly gets only the cells that went
+    dark reset -- frame after frame of a moving camera it must hold exactly what the full assembly (background fill +
+    cells) writes; a buffer, background or image-size change in between starts over by itself."""
+    import torch
+    from sgrt_amd import scene
+    g = scene.grid_scene(16)
+    world, tiles_n = 3, 8
+    st = torch.cuda.current_stream().cuda_stream
+    ranks = []
+    try:
+        for rk in range(world):
+            r = pkg.Renderer(0)
+            r.set_gaussians(g)
+            r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+            r.set_shard(rk, world)
+            ranks.append(r)
+        bufs = {}
+        steps = [(512, 0.0, "mode8", 0), (512, 9.0, "mode8", 0), (512, 31.0, "mode8", 0), (512, 31.0, "mode8", 0), (512, 77.0, "mode8", 0),
+                 (512, 80.0, "opaque", 0), (512, 95.0, "opaque", 0), (512, 95.0, "opaque", 1), (512, 120.0, "opaque", 1),
+                 (384, 120.0, "opaque", 0), (384, 160.0, "opaque", 0), (512, 10.0, "mode8", 0), (512, 200.0, "mode8", 0)]
+        lit = set()
+        for w, rot, pack_name, which in steps:
+            pack = pkg.PACK_ROUND | (pkg.ALPHA_COMPUTED if pack_name == "mode8" else pkg.ALPHA_OPAQUE)
+            cam, _ = scene.cli_camera(w, w, initial_rot=rot)
+            shards = []
+            for r in ranks:
+                r.set_camera_view(w, w, cam.view)
+                r.tile_gaussians_device(2.0 / tiles_n, 2.0 / tiles_n, cam.view, st)
+                buf = torch.zeros(r.sparse_shard_words(), dtype=torch.int32, device="cuda")
+                r.frame_sparse_call(2.0 / tiles_n, 2.0 / tiles_n, cam.view, cam.position, pack)(buf.data_ptr(), st)
+                shards.append(buf)
+            ptrs = [b.data_ptr() for b in shards]
+            want = torch.full((w * w,), 0x77, dtype=torch.int32, device="cuda")
+            ranks[0].scatter_sparse_device(ptrs, pack, want.data_ptr(), st)
+            # the retained buffers live as long as the test: one per (size, which) -- a smaller image after a larger one
+            # takes another buffer, as a caller's would
+            key = (w, which)
+            if key not in bufs:
+                bufs[key] = torch.full((w * w,), 0x11, dtype=torch.int32, device="cuda")
+            got = bufs[key]
+            ranks[0].scatter_sparse_device(ptrs, pack, got.data_ptr(), st, retained=True)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy(), err_msg=f"{(w, rot, pack_name, which)}")
+            lit.add(int((want != (0 if pack_name == "mode8" else -16777216)).sum().item()))
+        assert len(lit) > 3                                  # the lit area really changed between frames
+    finally:
+        for r in ranks:
+            r.close()
+
+
+def test_batch_assembly_equals_frame_by_frame(pkg, renderer):
+    """vrt_hip_scatter_sparse_batch_device: F frames from [rank][frame][words] buffers into F frame buffers with one launch,
+    retained per buffer -- three rounds of moving cameras, every frame equal to its plain assembly."""
+    import torch
+    from sgrt_amd import scene
+    g = scene.grid_scene(16)
+    world, tiles_n, F, w = 3, 8, 3, 384
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    st = torch.cuda.current_stream().cuda_stream
+    ranks = []
+    try:
+        for rk in range(world):
+            r = pkg.Renderer(0)
+            r.set_gaussians(g)
+            r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+            r.set_shard(rk, world)
+            ranks.append(r)
+        cam0, _ = scene.cli_camera(w, w)
+        for r in ranks:
+            r.set_camera_view(w, w, cam0.view)
+            r.tile_gaussians_device(2.0 / tiles_n, 2.0 / tiles_n, cam0.view, st)
+        words = ranks[0].sparse_shard_words()
+        assert words % 4 == 0
+        bufs = [torch.zeros(F * words, dtype=torch.int32, device="cuda") for _ in range(world)]
+        images = [torch.full((w * w,), 0x11, dtype=torch.int32, device="cuda") for _ in range(F)]
+        for rnd in range(3):
+            want = []
+            for f in range(F):
+                cam, _ = scene.cli_camera(w, w, initial_rot=50.0 * rnd + 13.0 * f)
+                for r, b in zip(ranks, bufs):
+                    r.set_camera_view(w, w, cam.view)
+                    r.frame_sparse_call(2.0 / tiles_n, 2.0 / tiles_n, cam.view, cam.position, pack)(b.data_ptr() + 4 * f * words, st)
+                full = torch.full((w * w,), 0x77, dtype=torch.int32, device="cuda")
+                ranks[0].scatter_sparse_device([b.data_ptr() + 4 * f * words for b in bufs], pack, full.data_ptr(), st)
+                want.append(full)
+            ranks[0].scatter_sparse_batch_device([b.data_ptr() for b in bufs], words, F, pack, [im.data_ptr() for im in images], st, retained=True)
+            torch.cuda.synchronize()
+            for f in range(F):
+                np.testing.assert_array_equal(images[f].cpu().numpy(), want[f].cpu().numpy(), err_msg=f"round {rnd} frame {f}")
+        with pytest.raises(pkg.VrtHipError, match="one buffer"):
+            ranks[0].scatter_sparse_batch_device([b.data_ptr() for b in bufs], words, 2, pack, [images[0].data_ptr()] * 2, st)
+    finally:
+        for r in ranks:
+            r.close()
+
+
 def test_group_frames_on_one_device(pkg, renderer):
     """vrt_hip_group with 1, 2 and 3 members on device 0: group_frame == the single-context frame; a second frame with
     another camera enqueued right behind the first (shard buffers are reused: the group orders that itself)."""
