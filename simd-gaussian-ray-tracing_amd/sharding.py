@@ -221,18 +221,19 @@ class SparseFrameGatherer:
     words    u32 per shard buffer (vrt_hip_sparse_shard_words(), the same on every rank); cap: its capacity in cells
     """
 
-    def __init__(self, dist, rank, world, words, cap, frames, device, stage=False):
+    def __init__(self, dist, rank, world, words, cap, frames, device, stage=False, nbuf=2):
         import torch
         self.dist, self.rank, self.world, self.words, self.cap = dist, rank, world, int(words), int(cap)
         self.F, self.stage, self.device = max(1, int(frames)), stage, device
         self.P = sparse_pixel_offset(self.cap)
-        self.shard = [torch.zeros(self.F * self.words, dtype=torch.int32, device=device) for _ in range(2)]
-        self.recv = [None, None]     # rank 0: [world, nf, prefix] of the batch in flight
-        self.prefix = [0, 0]
-        self.sent = [None, None]     # CUDA event: the send copy of buffer b's last batch has been taken
-        self.cells_sent = [0, 0]     # cells of the prefix that travelled for the batch in buffer b
-        self.most = [None, None]     # pinned host copy of the batch's all-reduced fullest shard (None: known, fits)
-        self.most_ready = [None, None]
+        self.NB = NB = max(2, int(nbuf))   # batches in flight: one being rendered, the others travelling / being assembled
+        self.shard = [torch.zeros(self.F * self.words, dtype=torch.int32, device=device) for _ in range(NB)]
+        self.recv = [None] * NB      # rank 0: [world, nf, prefix] of the batch in flight
+        self.prefix = [0] * NB
+        self.sent = [None] * NB      # CUDA event: the send copy of buffer b's last batch has been taken
+        self.cells_sent = [0] * NB   # cells of the prefix that travelled for the batch in buffer b
+        self.most = [None] * NB      # pinned host copy of the batch's all-reduced fullest shard (None: known, fits)
+        self.most_ready = [None] * NB
         self.cells_hint = None       # fullest shard seen so far (all ranks agree: it is all-reduced)
         self.regathered = 0
         self.bytes_moved = 0
@@ -296,7 +297,8 @@ class SparseFrameGatherer:
         """nsteps frames: render(b, f) fills shard_frame(b, f) -- or render_batch(b, nf) the first nf frames of buffer b at
         once; assemble(b, f) is called on rank 0 for every gathered frame -- or assemble_batch(b, nf) once per batch (frame
         f's shard of rank q is recv[b][q, f]: base recv[b][q], frame stride prefix[b] words)."""
-        pending, nfs, busy = [None, None], [0, 0], [False, False]
+        NB = self.NB
+        pending, nfs, busy, order = [None] * NB, [0] * NB, [False] * NB, []
 
         def finish(b):
             if pending[b] is not None:
@@ -322,8 +324,9 @@ class SparseFrameGatherer:
 
         F = self.F
         for i in range((nsteps + F - 1) // F):
-            b, nf = i & 1, min(F, nsteps - i * F)
+            b, nf = i % NB, min(F, nsteps - i * F)
             if busy[b]:
+                order.remove(b)
                 finish(b)
             if render_batch is not None:
                 render_batch(b, nf)
@@ -331,8 +334,8 @@ class SparseFrameGatherer:
                 for f in range(nf):
                     render(b, f)
             nfs[b], pending[b], busy[b] = nf, self.start(b, nf), True
-            if busy[1 - b]:
-                finish(1 - b)
-        for b in (0, 1):
-            if busy[b]:
-                finish(b)
+            order.append(b)
+            while len(order) > NB - 1:            # oldest first: frames are assembled in the order they were rendered
+                finish(order.pop(0))
+        while order:
+            finish(order.pop(0))

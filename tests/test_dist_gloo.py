@@ -148,7 +148,7 @@ def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather, 
             blob = ((yy - (20 + 9 * k) % h) ** 2 + (xx - (30 + 31 * k) % w) ** 2) < radius ** 2
             return np.where(blob, (np.uint32(0x01000000) + (yy * w + xx + k).astype(np.uint32)), np.uint32(0)).astype(np.uint32)
 
-        fg = sharding.SparseFrameGatherer(dist, rank, world, words, cap, frames_per_gather, "cpu")
+        fg = sharding.SparseFrameGatherer(dist, rank, world, words, cap, frames_per_gather, "cpu", nbuf=2 if world == 8 else 3)
         which, counter, frames = {}, [0], []
 
         def render(b, f):
