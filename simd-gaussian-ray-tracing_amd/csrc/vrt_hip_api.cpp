@@ -112,7 +112,10 @@ struct vrt_hip_ctx {
     uint32_t *d_fb = nullptr;
     // dense-launch sizing: frame_seq counts render launches; a report in h_fb[3] (the sequence number of the frame
     // that wrote it) newer than reset_seq comes from the current scene / camera / options
-    uint32_t frame_seq = 0, reset_seq = 0;
+    // A camera that moved keeps the reports (an orbit changes the picture gradually) but widens the idle launch until a
+    // report from the new pose has arrived (cam_seq): a jump to a pose with dense cells costs one frame at a quarter of
+    // the GPU, not one frame on one workgroup.
+    uint32_t frame_seq = 0, reset_seq = 0, cam_seq = 0;
     int num_cus = 256;
     float table_hx = 0.f;  // vrt_hip_set_table_step(): 0 = the exact kernels only
     int dense_idle_grid = 1; // workgroups of the dense launch when nothing is expected for it (VRT_HIP_DENSE_IDLE_GRID): one
@@ -627,7 +630,11 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     // launched at least two frames after the last change of scene, rays, camera or options, and it says "nothing",
     // the launch shrinks to one workgroup and skips the sort.  A wrong guess costs speed only.
     bool expect_dense = true;
-    if (c->h_fb && !c->stats_on && (int32_t)(c->h_fb[3] - c->reset_seq) >= 2) expect_dense = c->h_fb[0] > 0 || c->h_fb[2] > 0;
+    bool camera_moved = false;
+    if (c->h_fb && !c->stats_on && (int32_t)(c->h_fb[3] - c->reset_seq) >= 2) {
+        expect_dense = c->h_fb[0] > 0 || c->h_fb[2] > 0;
+        camera_moved = (int32_t)(c->h_fb[3] - c->cam_seq) < 2;
+    }
     CellGrid cg = cell_grid(c);
     cg.dense_is_sorted = expect_dense ? 1 : 0;
     cg.frame_seq = ++c->frame_seq;
@@ -643,7 +650,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         if (c->table_hx > 0.f || c->render_nw != 1)
             return fail(c, VRT_HIP_ERR_INVALID, "frame batch: table mode and two waves per block are not batched");
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
-        if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)c->dense_idle_grid);
+        if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
         FrameArgs &fa = *c->defer;
         fa.S = tables(c); fa.T = t; fa.C = cg; fa.R = ray_gen(c, origin); fa.O = o;
         c->deferred.render = true; c->deferred.render_grid = grid; c->deferred.order = expect_dense; c->deferred.dense_grid = dense_grid;
@@ -656,7 +663,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (expect_dense) launch_order_dense(cg, st);
     {
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
-        if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)c->dense_idle_grid);
+        if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
         if (c->table_hx > 0.f) {
             // opt-in table mode: the table kernel takes the whole dense queue and hands what it declines to a second
             // queue, which the exact kernel then works off (n_dense reads the always-zero word of the counter set)
@@ -904,7 +911,7 @@ int vrt_hip_tile_gaussians_device(vrt_hip_ctx *c, float tw, float th, const floa
     if (c->tile_mode != TILES_DEVICE || c->grid_tw != tw || c->grid_th != th || c->grid_n != c->n) {
         if ((rc = prepare_tile_grid(c, tw, th))) return rc; // waits for frames in flight (quiesce)
     }
-    if (memcmp(c->view, view, 16 * sizeof(float))) c->reset_seq = c->frame_seq;
+    if (memcmp(c->view, view, 16 * sizeof(float))) c->cam_seq = c->frame_seq;
     memcpy(c->view, view, 16 * sizeof(float));
     c->lists_dirty = true;
     c->ref_valid = false;
@@ -998,7 +1005,7 @@ int vrt_hip_set_camera(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float pos[3
     if (!w || !h || !pos || !right || !up || !front) return fail(c, VRT_HIP_ERR_INVALID, "set_camera: bad argument");
     if (c->w != w || c->h != h || c->plane_mode || c->focal != focal || memcmp(c->cam_pos, pos, 12) || memcmp(c->cam_right, right, 12) ||
         memcmp(c->cam_up, up, 12) || memcmp(c->cam_front, front, 12))
-        c->reset_seq = c->frame_seq; // another camera: earlier frames' reports say nothing about the next one
+        (c->w != w || c->h != h ? c->reset_seq : c->cam_seq) = c->frame_seq; // another camera / another image size
     memcpy(c->cam_pos, pos, 12); memcpy(c->cam_right, right, 12); memcpy(c->cam_up, up, 12); memcpy(c->cam_front, front, 12);
     c->focal = focal; c->w = w; c->h = h; c->plane_mode = false; c->view_mode = false; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
@@ -1013,7 +1020,7 @@ int vrt_hip_set_camera_view(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float 
     for (int i = 0; i < 16; ++i)
         if (!std::isfinite(inv[i])) return fail(c, VRT_HIP_ERR_INVALID, "set_camera_view: the view matrix is singular");
     if (c->w != w || c->h != h || c->plane_mode || !c->view_mode || memcmp(c->inv_view, inv, sizeof inv))
-        c->reset_seq = c->frame_seq; // another camera: earlier frames' reports say nothing about the next one
+        (c->w != w || c->h != h ? c->reset_seq : c->cam_seq) = c->frame_seq; // another camera / another image size
     memcpy(c->inv_view, inv, sizeof inv);
     c->w = w; c->h = h; c->plane_mode = false; c->view_mode = true; c->rays_set = true; c->lists_dirty = true;
     return VRT_HIP_OK;
