@@ -146,6 +146,43 @@ def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
     }
 
 
+def pick_streams(n, frame_a, frame_b, fixed=()):
+    """n HIP streams that overlap pairwise (and with the streams in `fixed`).  The HIP runtime runs all streams of a process
+    on a handful of hardware queues (four by default; a stream gets one when it is first used), and two streams on one
+    queue execute strictly one after the other: measured with this workload (`profiles/r02_stream_pairs.txt`), frames
+    alternating between torch's pool streams i and i + 4 take the serial 48.8 us per frame, any other pair 32.7.  Which
+    streams collide depends on everything the process created before, so the choice is made by measurement: candidates
+    are probed against the streams already chosen with the workload itself (frame_a(stream), frame_b(stream): one frame
+    each on two different contexts; 48 frames per probe)."""
+    import torch
+
+    def span(sa, sb, k=48):
+        for i in range(8):
+            (frame_a if i % 2 == 0 else frame_b)((sa if i % 2 == 0 else sb).cuda_stream)
+        sa.synchronize(); sb.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            (frame_a if i % 2 == 0 else frame_b)((sa if i % 2 == 0 else sb).cuda_stream)
+        sa.synchronize(); sb.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    cands = [torch.cuda.Stream() for _ in range(12)]
+    serial = min(span(cands[0], cands[0]) for _ in range(2))
+    chosen, log = [], []
+    for c in cands:
+        ts = [span(c, o) for o in list(fixed) + chosen]
+        ok = all(t < 0.85 * serial for t in ts)
+        log.append((round(serial * 1e6, 1), [round(t * 1e6, 1) for t in ts], ok))
+        if ok:
+            chosen.append(c)
+        if len(chosen) == n:
+            break
+    for c in cands:                       # fewer hardware queues than streams asked for: fill up
+        if len(chosen) < n and c not in chosen:
+            chosen.append(c)
+    return chosen, log
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +193,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=16)
     ap.add_argument("--cull-eps", type=float, default=1e-9)
     ap.add_argument("--gather-frames", type=int, default=32, help="N > 1: frames per RCCL gather (one collective per batch)")
+    ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
     ap.add_argument("--setup-ms", type=float, default=50.0, help="untimed set-up frames before the warm-up steps, in milliseconds of wall time")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: launch every frame of a gather batch on its own (round-2 baseline)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
@@ -230,18 +268,24 @@ def main():
     # every context on a stream of its own; with one context per rank (N > 1, tile sharding) it is torch's current stream,
     # which the collective and the assembly are ordered with (the legacy default stream as one of SEVERAL frame streams
     # costs throughput: 42.5 instead of ~36 us per frame with four contexts)
-    streams = ([torch.cuda.Stream() for _ in range(nctx)] if (solo and nctx > 1 and not os.environ.get("VRT_BENCH_DEFAULT_STREAM"))
-               else [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nctx - 1)])
-    sps = [s_.cuda_stream for s_ in streams]
-    sp = sps[0]
-    for r_, sp_ in zip(ctxs, sps):
-        r_.tile_gaussians_device(tw, th, view, sp_)   # also sizes the tile grid (one-time host sync)
+    for r_ in ctxs:
+        r_.tile_gaussians_device(tw, th, view, 0)     # also sizes the tile grid (one-time host sync)
     torch.cuda.synchronize()
-
     images = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(nctx)]
     image = images[0]
     frames = [r_.frame_call(tw, th, view, origin, pack, shard=not solo) for r_ in ctxs]   # tile_gaussians + render, one C call
     frame = frames[0]
+    stream_probe = None
+    if solo and nctx > 1 and not os.environ.get("VRT_BENCH_DEFAULT_STREAM"):
+        if args.no_stream_probe:
+            streams = [torch.cuda.Stream() for _ in range(nctx)]
+        else:
+            streams, stream_probe = pick_streams(nctx, lambda st_: frames[0](images[0].data_ptr(), st_),
+                                                 lambda st_: frames[1](images[1].data_ptr(), st_))
+    else:
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nctx - 1)]
+    sps = [s_.cuda_stream for s_ in streams]
+    sp = sps[0]
     img_ptrs = [im.data_ptr() for im in images]
     img_ptr = img_ptrs[0]
     # N > 1: sharding.SparseFrameGatherer -- every rank renders its tile shard of F consecutive frames as SPARSE shards
@@ -283,7 +327,13 @@ def main():
                                               retained=True)
 
             groups = [[r] + [make_renderer() for _ in range(F - 1)]] + [[make_renderer() for _ in range(F)] for _ in range(NB - 1)]
-            rstreams = [torch.cuda.Stream() for _ in range(NB)]
+            if args.no_stream_probe:
+                rstreams = [torch.cuda.Stream() for _ in range(NB)]
+            else:
+                pa = groups[0][0].frame_sparse_call(tw, th, view, origin, pack)
+                pb = groups[1][0].frame_sparse_call(tw, th, view, origin, pack)
+                rstreams, stream_probe = pick_streams(NB, lambda st_: pa(shard_ptr[0], st_), lambda st_: pb(shard_ptr[1], st_),
+                                                      fixed=[torch.cuda.current_stream()])
             for gr in groups:
                 for r_ in gr[1:] if gr[0] is r else gr:
                     r_.tile_gaussians_device(tw, th, view, sp)
@@ -485,6 +535,7 @@ def main():
                                            fg.bytes_moved / max(1, fg.frames_moved), "compact_shards_would_be": (world - 1) * w * h * 4 // world,
                                            "batches_gathered_twice": fg.regathered}),
                        "frames_in_flight": nctx,
+                       "stream_probe_us_per_frame": stream_probe,
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": render_gbs / HBM_PEAK_GBS, "traffic": traffic,
