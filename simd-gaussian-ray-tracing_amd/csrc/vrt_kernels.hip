@@ -306,6 +306,31 @@ __device__ __forceinline__ void shade_lanes(const float4 *s_A, const float4 *s_B
     }
 }
 
+// The same with balanced chunks of at most ECMAX emitters: ceil(nmax / ECMAX) chunks of nearly equal size, so that a list
+// of 5 is ONE pass over the absorbers (not 4 + 1) and a list of 9 is 5 + 4 (not 4 + 4 + 1).  Emitters and absorbers are
+// visited in the same order as before: the sums are bit-identical.
+#ifndef VRT_RENDER_ECMAX
+#define VRT_RENDER_ECMAX 4
+#endif
+template <int EXP, int ERF, int ECMAX>
+__device__ __forceinline__ void shade_lanes_balanced(const float4 *s_A, const float4 *s_B, const float4 *s_M, const float4 *s_C,
+                                                     const float *s_q, const uint8_t *s_lane, uint32_t nl, uint32_t nmax, uint32_t lane,
+                                                     const LaneRay &ray, float &Lr, float &Lg, float &Lb, float &La)
+{
+    Lr = Lg = Lb = La = 0.f;
+    uint32_t chunks = (nmax + ECMAX - 1) / ECMAX;
+    for (uint32_t i0 = 0; i0 < nmax; --chunks) {
+        const uint32_t size = (nmax - i0 + chunks - 1) / chunks;
+        if (ECMAX >= 6 && size == 6) shade_chunk<EXP, ERF, (ECMAX >= 6 ? 6 : 1)>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else if (ECMAX >= 5 && size == 5) shade_chunk<EXP, ERF, (ECMAX >= 5 ? 5 : 1)>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else if (size == 4) shade_chunk<EXP, ERF, 4>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else if (size == 3) shade_chunk<EXP, ERF, 3>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else if (size == 2) shade_chunk<EXP, ERF, 2>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        else shade_chunk<EXP, ERF, 1>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
+        i0 += size;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rays and cones
 // ---------------------------------------------------------------------------------------------
@@ -692,7 +717,8 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
         float Lr, Lg, Lb, La;
         if constexpr (NW == 1) {
-            shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+            if constexpr (VRT_RENDER_ECMAX > 4) shade_lanes_balanced<EXP, ERF, VRT_RENDER_ECMAX>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+            else shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
             write_block(Lr, Lg, Lb, La, valid, out);
         } else {
             // emitters: up to 2*EC of them are cut in two halves, one chunk per wave; longer lists alternate chunks of EC

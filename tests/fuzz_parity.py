@@ -18,6 +18,8 @@ pkg = load_pkg()
 import oracle as O
 O.build()
 r = pkg.Renderer(0)
+batch_ctxs = [pkg.Renderer(0) for _ in range(3)]
+retained_imgs = {}
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 worst = 0.0
@@ -108,6 +110,43 @@ for case in range(ncase):
         extra = f"  host tiles {'==' if ok_h else '!='}  shards x{world} {'==' if ok_s else '!='}  sparse shards {'==' if ok_p else '!='}"
         if not (ok_h and ok_s and ok_p):
             errb = max(errb, 1.0)
+        # the same frame three times in ONE launch of each kernel (frame batch on three contexts), then the sparse shards of
+        # one rank as a batch, assembled with the batched retained assembly into buffers that hold the previous case
+        for x in batch_ctxs:
+            x.set_gaussians(g); x.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps); x.set_table_step(0.0); x.set_shard(0, 1)
+            x.set_camera_view(w, h, view)
+        try:
+            pk = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+            outs = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in batch_ctxs]
+            batch_ctxs[0].frame_batch_call(batch_ctxs[1:], 2.0 / tiles_n, 2.0 / tiles_n, [view] * 3, [origin] * 3, pk)([o_.data_ptr() for o_ in outs], st)
+            torch.cuda.synchronize()
+            ok_b = all(bool((o_.cpu().numpy().view(np.uint32).reshape(h, w) == img).all()) for o_ in outs)
+            rk = int(rng.integers(0, world))
+            for x in batch_ctxs:
+                x.set_shard(rk, world); x.tile_gaussians_device(2.0 / tiles_n, 2.0 / tiles_n, view, st)
+            words = max(batch_ctxs[0].sparse_shard_words(), 4)
+            bb = torch.full((3 * words,), -1, dtype=torch.int32, device="cuda")
+            batch_ctxs[0].frame_batch_call(batch_ctxs[1:], 2.0 / tiles_n, 2.0 / tiles_n, [view] * 3, [origin] * 3, pk, out_kind=2)(
+                [bb.data_ptr() + 4 * words * f for f in range(3)], st)
+            ptrs = [b.data_ptr() for b in sparse]
+            if (w, h) not in retained_imgs:
+                retained_imgs[(w, h)] = [torch.full((w * h,), 0x33, dtype=torch.int32, device="cuda") for _ in range(3)]
+            ri = retained_imgs[(w, h)]
+            # frame f of the batch: rank rk's shard from the batch, the other ranks' from the frame-by-frame run above
+            r.set_shard(rk, world); r.tile_gaussians_device(2.0 / tiles_n, 2.0 / tiles_n, view, st)   # any rank of the job: the shard capacity is the job's
+            for f in range(3):
+                pf = list(ptrs); pf[rk] = bb.data_ptr() + 4 * words * f
+                r.scatter_sparse_device(pf, pk, ri[f].data_ptr(), st, retained=True)
+            torch.cuda.synchronize()
+            ok_b = ok_b and all(bool((o_.cpu().numpy().view(np.uint32).reshape(h, w) == img).all()) for o_ in ri)
+            extra += f"  batch x3 {'==' if ok_b else '!='}"
+            if not ok_b:
+                errb = max(errb, 1.0)
+        except pkg.VrtHipError as e:
+            if "not batched" not in str(e):
+                raise
+            extra += "  batch n/a"
+        r.set_shard(0, 1)
     # (d) every fourth case: the point queries against the oracle (rt.h:32-54, 146-223; rt.cpp:8-27)
     if case % 4 == 1 and n <= 600:
         ek, rk = [(pkg.EXP_VCL, pkg.ERF_AS), (pkg.EXP_LIBM, pkg.ERF_LIBM), (pkg.EXP_LIBM, pkg.ERF_AS)][case % 3]
