@@ -96,6 +96,12 @@ struct vrt_hip_ctx {
         DevBuf<uint32_t> stamp;
     };
     std::vector<Retained> retained; // one history per frame buffer (at most MAX_ASSEMBLY_FRAMES, oldest dropped)
+    // tile cones of the list kernel: a function of the rays and the tile geometry only, kept across frames (cone_key =
+    // what they were made for; VRT_HIP_TILE_CONES=0: every workgroup builds its own, as before)
+    DevBuf<float4> tile_cones;
+    std::string cone_key;
+    uint32_t plane_gen = 0;
+    bool cache_cones = true;
     float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
@@ -426,6 +432,18 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         a.cull_ref_n = c->cull_ref_n; a.floor_x = exp_floor_x(c->exp_kind);
         a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
     }
+    if (refine && c->cache_cones) {
+        std::string key((const char *)&a.R, sizeof a.R);
+        const uint32_t geo_key[6] = { geo.tile_w, geo.tile_h, geo.stride, geo.tiles_w, geo.tiles_h, c->plane_gen };
+        key.append((const char *)geo_key, sizeof geo_key);
+        a.tiles_w = geo.tiles_w;
+        if (key != c->cone_key || c->tile_cones.cap < 2 * nt) {
+            HIPCHK(c, c->tile_cones.reserve(2 * nt));
+            launch_tile_cones(a, geo.tiles_h, c->tile_cones.p, st);
+            c->cone_key = key;
+        }
+        a.tile_cones = c->tile_cones.p;
+    }
     const bool device_bin = c->tile_mode == TILES_DEVICE;
     // one fused kernel when a tile's cells fit one workgroup's waves; otherwise tile kernel + one-wave-per-cell kernel
     const bool fuse = c->cells_x * c->cells_y <= (uint32_t)MAX_FUSED_CELLS && (device_bin || refine);
@@ -742,6 +760,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
     }
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
+    if (const char *e = getenv("VRT_HIP_TILE_CONES")) c->cache_cones = atoi(e) != 0;
     if (const char *e = getenv("VRT_HIP_DENSE_IDLE_GRID")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 256) c->dense_idle_grid = v;
@@ -768,7 +787,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)quiesce(c); // frames still in flight on the context's stream or on the caller's last stream read these buffers
     for (auto &b : c->soa) b.release();
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
@@ -778,6 +797,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
     for (auto &r : c->retained) r.stamp.release();
+    c->tile_cones.release();
     if (c->batch_host) (void)hipHostFree(c->batch_host);
     if (c->batch_dev) (void)hipFree(c->batch_dev);
     for (auto &e : c->batch_copied) if (e) (void)hipEventDestroy(e);
@@ -995,6 +1015,7 @@ int vrt_hip_set_plane(vrt_hip_ctx *c, uint32_t w, uint32_t h, const float *xs, c
     c->plane_affine = plane_is_affine(w, h, xs, ys, zs);
     c->reset_seq = c->frame_seq; // new rays
     c->w = w; c->h = h; c->plane_mode = true; c->rays_set = true; c->lists_dirty = true;
+    ++c->plane_gen; // other plane arrays behind the same pointers: the tile cones are no longer theirs
     return VRT_HIP_OK;
 }
 

@@ -1433,6 +1433,35 @@ void launch_iota(uint32_t *p, uint32_t n, hipStream_t st)
 // (index + the two parameter rows the cone test reads) and each of its 16 waves filters them for the tile's
 // 32x32-pixel cells, files every non-empty cell as active or dense (at most two atomics per TILE) and clears the
 // pixels of empty cells on the spot -- no second kernel, no global round trip, no idle clear phase later.
+// cone of a whole reference tile, from the centre and the four corner pixels (pinhole rays: the farthest ray of a rectangle
+// on the image plane from its centre ray is a corner ray)
+__device__ __forceinline__ Cone tile_cone(const BinArgs &P, uint32_t tx, uint32_t ty, uint32_t lane)
+{
+    const uint64_t npix0 = (uint64_t)P.R.width * P.R.height;
+    auto at = [&](uint32_t x, uint32_t y) {
+        uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
+        if (pix >= npix0) pix = npix0 - 1;
+        return cone_ray(P.R, pix);
+    };
+    return rect_cone(at, 0, 0, P.tile_w - 1, P.tile_h - 1, lane);
+}
+// one wave per tile id: the cones the list kernel would build per workgroup (16 waves each), once per camera
+__global__ __launch_bounds__(256) void tile_cones_kernel(BinArgs P, uint32_t n_tiles, float4 *out)
+{
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const Cone c = tile_cone(P, t % P.tiles_w, t / P.tiles_w, lane);
+    if (lane == 0) {
+        out[2 * t] = make_float4(c.cx, c.cy, c.cz, c.cos_t);
+        out[2 * t + 1] = make_float4(c.sin_t, 0.f, 0.f, 0.f);
+    }
+}
+void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, float4 *cones_out, hipStream_t st)
+{
+    const uint32_t n_tiles = a.tiles_w * tiles_h;
+    if (n_tiles) hipLaunchKernelGGL(tile_cones_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, a, n_tiles, cones_out);
+}
+
 template <bool FROM_LIST>
 __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const FuseArgs &F)
 {
@@ -1485,13 +1514,12 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
     Cone cone = {};
     if (P.refine) {
-        const uint64_t npix0 = (uint64_t)P.R.width * P.R.height;
-        auto at = [&](uint32_t x, uint32_t y) {
-            uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
-            if (pix >= npix0) pix = npix0 - 1;
-            return cone_ray(P.R, pix);
-        };
-        cone = rect_cone(at, 0, 0, P.tile_w - 1, P.tile_h - 1, lane);
+        if (P.tile_cones) { // made once for this camera (tile_cones_kernel)
+            const float4 c0 = P.tile_cones[2 * t], c1 = P.tile_cones[2 * t + 1];
+            cone.cx = c0.x; cone.cy = c0.y; cone.cz = c0.z; cone.cos_t = c0.w; cone.sin_t = c1.x;
+        } else {
+            cone = tile_cone(P, tx, ty, lane);
+        }
     }
 
     if (tl) tl[1] = wall_clock64();
