@@ -7,7 +7,8 @@ Metric (BASELINE.json): Mrays/sec (whole node) + ms/frame, 2048^2 image, 64x64 G
 A step = one frame = what the reference times as `TIME:` (main.cpp:260-296): tile binning of all
 Gaussians + render (+ for N > 1: RCCL gather of the tile shards to rank 0 + assembly into raster
 order).  Inputs (scene tables, camera) are resident in HBM before the timed region starts.
-N = 1 keeps three frames in flight (three library contexts on three HIP streams, --frames-in-flight);
+N = 1 keeps four frames in flight (four library contexts on four HIP streams = the HIP runtime's four hardware queues,
+--frames-in-flight);
 the strictly serial figures are reported next to the headline under "serial".
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -196,7 +197,7 @@ def main():
     ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
     ap.add_argument("--setup-ms", type=float, default=50.0, help="untimed set-up frames before the warm-up steps, in milliseconds of wall time")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: launch every frame of a gather batch on its own (round-2 baseline)")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial frames")
     ap.add_argument("--parallel", choices=["tiles", "frames"], default="tiles",
                     help="N > 1: 'tiles' = one frame's tiles sharded over the ranks + gather (the headline, SURVEY 8e); 'frames' = "
@@ -244,7 +245,8 @@ def main():
     tw = th = 2.0 / args.tiles
     pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
 
-    # N = 1: the frames alternate between `--frames-in-flight` library contexts, each on its own HIP stream (default 3):
+    # N = 1: the frames alternate between `--frames-in-flight` library contexts, each on its own HIP stream (default 4: one per
+    # hardware queue of the HIP runtime; a fifth stream shares a queue with the first and serialises behind it):
     # frame k+1's list kernel and the head of its render kernel run while frame k's render kernel drains -- the
     # double-buffered frame loop of any renderer.  Every frame does all of its work; the strictly serial figures are
     # measured after the timed region and reported next to the headline ("serial").  N > 1: one context per rank
