@@ -486,7 +486,10 @@ def main():
                                 "lane_ops": 14 * culls + 16 * terms, "wave_instruction_equivalents": alg_wave_instr,
                                 "achieved_per_s": alg_wave_instr / (kernel_ms * 1e-3),
                                 "frac": alg_wave_instr / (kernel_ms * 1e-3) / VALU_PEAK_WAVE_INSTR,
-                                "frac_serial_launch": alg_wave_instr / (kt["render_serial_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTR},
+                                "frac_serial_launch": alg_wave_instr / (kt["render_serial_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTR,
+                                # per FRAME TIME of the timed region: what the GPU as a whole sustains with frames in flight
+                                # (a launch that shares the GPU with other frames' kernels lasts longer than its share of it)
+                                "frac_of_frame_time": (alg_wave_instr / (ms_per_step * 1e-3) / VALU_PEAK_WAVE_INSTR) if solo else None},
                 "peak_per_s": VALU_PEAK_WAVE_INSTR,
                 "peak_note": "spec: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
         try:
@@ -512,7 +515,8 @@ def main():
                                             "frac": rate / VALU_PEAK_WAVE_INSTR,
                                             "frac_serial_launch": nv / (kt["render_serial_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTR,
                                             "algorithmic_share": alg_wave_instr / nv,
-                                            "frame_wave_instructions": nv + nl}
+                                            "frame_wave_instructions": nv + nl,
+                                            "frame_frac_of_frame_time": ((nv + nl) / (ms_per_step * 1e-3) / VALU_PEAK_WAVE_INSTR) if solo else None}
                     valu["from"] = {"file": pmc_path, "kernel_source_sha": sha, "kind": "constants of separate --pmc passes"}
                 except KeyError:
                     traffic, traffic_frame = None, None
