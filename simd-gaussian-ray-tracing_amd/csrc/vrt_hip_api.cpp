@@ -523,10 +523,12 @@ TileLists work_lists(const vrt_hip_ctx *c)
 }
 
 // Owner of tile t = (tx, ty): the ranks form an a x b brick (a * b = world, a >= b as square as the divisors allow) that
-// tiles the tile grid, owner = tx % a + a * (ty % b).  Every a x b window of tiles holds every rank once, so an object that
-// covers a few tiles in the middle of the frame -- `-g 64 -w 2048` lights 4 x 4 of the 16 x 16 tiles -- is spread evenly:
-// the busiest of 8 ranks gets 14 % of its cells (ideal 12.5 %; dealing tiles along diagonals, as round 1 did, gave one
-// rank 25 %).  sharding.py mirrors this.
+// tiles the tile grid, every row of bricks shifted by half a brick against the one above:
+// owner = (tx + (a / 2) * (ty / b)) % a + a * (ty % b).  Every a x b window of tiles, wherever it lies, holds every rank once,
+// so an object that covers a few tiles in the middle of the frame -- `-g 64 -w 2048` lights 4 x 4 of the 16 x 16 tiles, the
+// outer ones partly -- is spread evenly: the busiest of 8 ranks gets 12.8 % of its cells (ideal 12.5 %; unshifted bricks
+// 14.3 %, because a rank's two tiles then share a column; dealing tiles along diagonals, as round 1 did, 25 %).
+// sharding.py mirrors this.
 inline int shard_owner(uint32_t t, uint32_t tiles_w, int world)
 {
     uint32_t b = 1;
@@ -534,7 +536,7 @@ inline int shard_owner(uint32_t t, uint32_t tiles_w, int world)
         if ((uint32_t)world % d == 0) b = d;
     const uint32_t a = (uint32_t)world / b;
     const uint32_t tx = t % tiles_w, ty = t / tiles_w;
-    return (int)(tx % a + a * (ty % b));
+    return (int)((tx + (a / 2) * (ty / b)) % a + a * (ty % b));
 }
 
 int rebuild_shard(vrt_hip_ctx *c)

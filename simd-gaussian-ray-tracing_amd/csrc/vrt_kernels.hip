@@ -1884,16 +1884,24 @@ __device__ __forceinline__ void clear_stale_cells_body(const uint32_t *stamp, ui
                                                        const TileLists &T, uint32_t cells_x, uint32_t cells_y, uint32_t width,
                                                        uint32_t height, uint32_t background)
 {
-    const uint32_t key = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (!stamp || key >= n_cells || stamp[key] != seq - 1) return;
+    // one cell per LANE to look at (a frame has thousands of cells and a handful of stale ones), the wave then clears the
+    // stale ones of its 64 one after the other
+    const uint32_t lane = threadIdx.x & 63, key0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (!stamp || key0 >= n_cells) return;
+    const uint32_t mine = key0 + lane;
+    unsigned long long stale = __ballot(mine < n_cells && stamp[mine] == seq - 1);
     const uint32_t cpt = cells_x * cells_y;
-    const uint32_t t = key / cpt, ci = key % cpt;
-    const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
     const uint64_t npix = (uint64_t)width * height;
-    for (uint32_t q = lane; q < CELL * CELL; q += 64) {
-        const uint32_t pxt = (ci % cells_x) * CELL + q % CELL, pyt = (ci / cells_x) * CELL + q / CELL;
-        const uint64_t pix = (uint64_t)(tx * T.tile_w + pxt) + (uint64_t)T.stride * (ty * T.tile_h + pyt);
-        if (pxt < T.tile_w && pyt < T.tile_h && pix < npix) image[pix] = background;
+    while (stale) {
+        const uint32_t key = key0 + (uint32_t)__builtin_ctzll(stale);
+        stale &= stale - 1;
+        const uint32_t t = key / cpt, ci = key % cpt;
+        const uint32_t tx = t % T.tiles_w, ty = t / T.tiles_w;
+        for (uint32_t q = lane; q < CELL * CELL; q += 64) {
+            const uint32_t pxt = (ci % cells_x) * CELL + q % CELL, pyt = (ci / cells_x) * CELL + q / CELL;
+            const uint64_t pix = (uint64_t)(tx * T.tile_w + pxt) + (uint64_t)T.stride * (ty * T.tile_h + pyt);
+            if (pxt < T.tile_w && pyt < T.tile_h && pix < npix) image[pix] = background;
+        }
     }
 }
 __global__ __launch_bounds__(256) void clear_stale_cells_kernel(const uint32_t *stamp, uint32_t seq, uint32_t n_cells, uint32_t *image,
@@ -1925,19 +1933,25 @@ void launch_assemble_sparse_batch(const ShardPtrs &shards, int nshards, size_t f
                                   uint32_t width, uint32_t height, uint32_t background, hipStream_t st)
 {
     if (nshards <= 0 || nframes <= 0 || !max_cells) return;
-    hipLaunchKernelGGL(scatter_sparse_batch_kernel, dim3(max_cells, (uint32_t)nshards, (uint32_t)nframes), dim3(256), 0, st, shards,
+    // a frame stride shorter than a whole shard (a gathered prefix) cannot hold more cells than fit in it: no workgroups for
+    // slots that did not travel
+    uint32_t slots = max_cells;
+    const size_t hdr = sparse_pixel_offset(max_cells);
+    if (frame_stride > hdr && frame_stride < hdr + (size_t)max_cells * (CELL * CELL))
+        slots = (uint32_t)std::max<size_t>(1, (frame_stride - hdr) / (CELL * CELL));
+    hipLaunchKernelGGL(scatter_sparse_batch_kernel, dim3(slots, (uint32_t)nshards, (uint32_t)nframes), dim3(256), 0, st, shards,
                        frame_stride, frames, max_cells, t, cells_x, cells_y, width, height);
     bool any = false;
     for (int f = 0; f < nframes; ++f) any = any || frames.clear[f];
     if (any && n_cells)
-        hipLaunchKernelGGL(clear_stale_cells_batch_kernel, dim3((n_cells + 3) / 4, (uint32_t)nframes), dim3(256), 0, st, frames, n_cells, t,
+        hipLaunchKernelGGL(clear_stale_cells_batch_kernel, dim3((n_cells + 255) / 256, (uint32_t)nframes), dim3(256), 0, st, frames, n_cells, t,
                            cells_x, cells_y, width, height, background);
 }
 void launch_clear_stale_cells(const uint32_t *stamp, uint32_t seq, uint32_t n_cells, uint32_t *image, const TileLists &t,
                               uint32_t cells_x, uint32_t cells_y, uint32_t width, uint32_t height, uint32_t background, hipStream_t st)
 {
     if (!n_cells) return;
-    hipLaunchKernelGGL(clear_stale_cells_kernel, dim3((n_cells + 3) / 4), dim3(256), 0, st, stamp, seq, n_cells, image, t, cells_x,
+    hipLaunchKernelGGL(clear_stale_cells_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, st, stamp, seq, n_cells, image, t, cells_x,
                        cells_y, width, height, background);
 }
 

@@ -2,8 +2,9 @@
 and of the shard-buffer layout, plus the gather protocol bench.py runs over RCCL.
 
 A frame's reference tiles (tiles_w x tiles_h, row-major tile id t = ty*tiles_w + tx, rt.cpp:47-51) are
-dealt to ranks in a x b bricks (a * b = world, as square as the divisors allow): owner(tx, ty) = tx % a + a * (ty % b),
-so that every a x b window of tiles holds every rank once.  Every rank renders its tiles
+dealt to ranks in a x b bricks (a * b = world, as square as the divisors allow), every row of bricks shifted by half a
+brick: owner(tx, ty) = (tx + (a // 2) * (ty // b)) % a + a * (ty % b), so that every a x b window of tiles holds every
+rank once and a rank's tiles do not line up in columns.  Every rank renders its tiles
 into a compact buffer [slot][tile_h][tile_w] (slots padded to the same count on every rank so that one
 fixed-size gather moves the frame); rank 0 scatters the rank-major concatenation into raster order --
 the copy loop of the reference's simd_render_image (rt.h:388-399).
@@ -18,7 +19,7 @@ def shard_owner(t, tiles_w, world):
     b = max(d for d in range(1, int(world ** 0.5) + 1) if world % d == 0)
     a = world // b
     ty, tx = divmod(t, tiles_w)
-    return tx % a + a * (ty % b)
+    return (tx + (a // 2) * (ty // b)) % a + a * (ty % b)
 
 
 def shard_table(tiles_w, tiles_h, world):

