@@ -1333,20 +1333,35 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
     FrameArgs *d_rows = c0->batch_dev + (size_t)slot * c0->batch_cap;
 
     // every frame's host work, memsets and per-origin table kernel as for a single frame; its three launches recorded
-    for (int i = 0; i < n; ++i) {
+    int failed = VRT_HIP_OK, touched = 0;
+    for (int i = 0; i < n && !failed; ++i) {
         vrt_hip_ctx *c = ctxs[i];
         c->defer = &rows[i];
         c->deferred = vrt_hip_ctx::Deferred{};
+        touched = i + 1;
         int rc = vrt_hip_tile_gaussians_device(c, tw, th, views + 16 * (size_t)i, hip_stream);
         if (!rc) rc = render_common(c, origins + 3 * (size_t)i, pack_flags, d_out[i], nullptr, st, out_kind);
         c->defer = nullptr;
         if (rc) {
             if (c != c0) fail(c0, rc, std::string("frame_batch: frame ") + std::to_string(i) + ": " + c->err);
-            return rc;
+            failed = rc;
+            break;
         }
         const auto &d = c->deferred, &d0 = c0->deferred;
         if (!d.render || d.lists != d0.lists || d.from_list != d0.from_list || d.list_grid != d0.list_grid || d.render_grid != d0.render_grid)
-            return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the frames differ in image size, tile grid, shard or scene size");
+            failed = fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the frames differ in image size, tile grid, shard or scene size");
+    }
+    if (failed) {
+        // The contexts prepared so far have advanced their list and queue generations for kernels that will not run: the
+        // counter sets those kernels would have cleared for the next frame are stale.  Clear them and make the next frame
+        // rebuild its lists.
+        for (int i = 0; i < touched; ++i) {
+            vrt_hip_ctx *c = ctxs[i];
+            if (c->c_counters.p && hipMemsetAsync(c->c_counters.p, 0, 16 * sizeof(uint32_t), st) != hipSuccess) (void)hipGetLastError();
+            if (c->c_rq.p && hipMemsetAsync(c->c_rq.p, 0, 2 * RQ_N * RQ_STRIDE * sizeof(uint32_t), st) != hipSuccess) (void)hipGetLastError();
+            c->lists_dirty = true; c->lists_fresh = false;
+        }
+        return failed;
     }
     HIPCHK(c0, hipMemcpyAsync(d_rows, rows, (size_t)n * sizeof(FrameArgs), hipMemcpyHostToDevice, st));
     HIPCHK(c0, hipEventRecord(c0->batch_copied[slot], st));

@@ -141,6 +141,14 @@ def test_batch_refusals(pkg, renderer):
     out = [torch.zeros(w * w, dtype=torch.int32, device="cuda") for _ in range(2)]
     ptrs = [o.data_ptr() for o in out]
     try:
+        # frames before the refusals: the contexts' list and queue generations are in use (a refused batch must leave them
+        # in a state from which the next frame is right)
+        for r_, o_ in zip(ctxs, out):
+            for _ in range(3):
+                r_.frame_call(2 / 4, 2 / 4, cam.view, cam.position, 0)(o_.data_ptr(), 0)
+        torch.cuda.synchronize()
+        before = out[0].clone()
+        assert int((before != 0).sum()) > 0 and bool((out[0] == out[1]).all())
         with pytest.raises(pkg.VrtHipError, match="own"):     # one context cannot hold two frames
             ctxs[0].frame_batch_call([ctxs[0]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
         ctxs[1].set_options(pkg.EXP_LIBM, pkg.ERF_LIBM, 1e-9)
@@ -157,10 +165,16 @@ def test_batch_refusals(pkg, renderer):
             ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
         for r in ctxs:
             r.set_table_step(0.0)
+        # single frames right after the refused batch (its contexts had advanced their generations for kernels that never ran)
+        for r_, o_ in zip(ctxs, out):
+            o_.zero_()
+            r_.frame_call(2 / 4, 2 / 4, cam.view, cam.position, 0)(o_.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert bool((out[0] == before).all()) and bool((out[1] == before).all())
         # and it still works afterwards
         ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
         torch.cuda.synchronize()
-        assert (out[0] == out[1]).all() and int((out[0] != 0).sum()) > 0
+        assert bool((out[0] == before).all()) and bool((out[1] == before).all())
     finally:
         for r in ctxs:
             r.close()
