@@ -133,10 +133,10 @@ static int run_on_group(const cmd_args_t &cmd, const std::vector<vrt::gaussian_t
     }
     if (devices.empty()) for (u64 i = 0; i < cmd.gpus; ++i) devices.push_back((int)i);
     devices.resize(cmd.gpus, devices.back());
-    // whole frames dealt to the members (no exchange) when no frame has to be in one place; three members per GPU then,
-    // like the three contexts of the single-GPU loop
+    // whole frames dealt to the members (no exchange) when no frame has to be in one place; four members per GPU then,
+    // like the four contexts of the single-GPU loop
     const bool deal_frames = cmd.outfile == nullptr && cmd.nr_frames > 1;
-    if (deal_frames) { const size_t n = devices.size(); for (size_t k = 0; k < 2 * n; ++k) devices.push_back(devices[k % n]); }
+    if (deal_frames) { const size_t n = devices.size(); for (size_t k = 0; k < 3 * n; ++k) devices.push_back(devices[k % n]); }
     vrt_hip_group *grp = nullptr;
     if (vrt_hip_group_create(devices.data(), (int)devices.size(), &grp) != VRT_HIP_OK) {
         fprintf(stderr, "[ ERROR ]\t%s\n", vrt_hip_group_last_error(nullptr));
@@ -251,11 +251,13 @@ int main(int argc, char **argv)
     if (cmd.gpus > 1 && use_tiling) return run_on_group(cmd, gaussians, pack, ek, rk);
     if (cmd.gpus > 1) fprintf(stderr, "[ INFO ]\t--gpus applies to the tiled modes (5-8): an untiled frame has no tiles to shard; using one GPU\n");
 
-    // An animation whose frames are not written out keeps three frames in flight: the frames alternate between three
+    // An animation whose frames are not written out keeps four frames in flight: the frames alternate between four
     // contexts (each has its own HIP stream), so one frame's list kernel and the tail of its block kernel overlap the
     // other frames' work (like bench.py).
-    const int nctx = (cmd.outfile == nullptr && cmd.nr_frames > 1 && getenv("VRT_CLI_TRACE") == nullptr) ? 3 : 1;
-    vrt_hip_ctx *ctxs[3] = { nullptr, nullptr, nullptr };
+    int in_flight = 4; // one per hardware queue of the HIP runtime (VRT_CLI_CONTEXTS=1..8 to try others)
+    if (const char *e = getenv("VRT_CLI_CONTEXTS")) in_flight = std::max(1, std::min(8, atoi(e)));
+    const int nctx = (cmd.outfile == nullptr && cmd.nr_frames > 1 && getenv("VRT_CLI_TRACE") == nullptr) ? in_flight : 1;
+    vrt_hip_ctx *ctxs[8] = {};
     const char *dev = getenv("VRT_HIP_DEVICE");
     for (int i = 0; i < nctx; ++i)
         if (vrt_hip_create(dev ? atoi(dev) : 0, &ctxs[i]) != VRT_HIP_OK) {
