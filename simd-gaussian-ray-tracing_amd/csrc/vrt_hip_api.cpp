@@ -102,6 +102,7 @@ struct vrt_hip_ctx {
     std::string cone_key;
     uint32_t plane_gen = 0;
     bool cache_cones = true;
+    bool skip_idle_dense = true; // VRT_HIP_DENSE_SKIP=0: the dense kernel is launched behind every block kernel
     float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
@@ -248,7 +249,7 @@ int prep_frame(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
     launch_prep_frame(tables(c), c->gA.p, origin, st);
     HIPCHK(c, hipGetLastError());
     memcpy(c->gA_origin, origin, 3 * sizeof(float));
-    c->reset_seq = c->frame_seq;
+    c->cam_seq = c->frame_seq; // the camera moved
     c->gA_valid = true;
     c->lists_dirty = true; // the tile-level cull depends on the origin
     return VRT_HIP_OK;
@@ -655,6 +656,16 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         expect_dense = c->h_fb[0] > 0 || c->h_fb[2] > 0;
         camera_moved = (int32_t)(c->h_fb[3] - c->cam_seq) < 2;
     }
+    // Not a guess: which blocks are dense is a function of scene, options, rays, camera, tile grid and shard.  A report
+    // from a frame that was launched AFTER the last change of any of them (sequence number above reset_seq and cam_seq)
+    // and that found no dense cell and no handed-over block says the same of this frame: the dense launch -- 4.7 us of a
+    // 47-us serial frame even for one idle workgroup, which also waits for 61 KB of LDS while other frames' block kernels
+    // fill the CUs -- is left out.  Any change brings it back until a frame of the new state has reported.
+    bool no_dense_work = false;
+    if (c->skip_idle_dense && c->h_fb && !c->stats_on) {
+        const uint32_t seen = c->h_fb[3]; // read first: what is read after it is at least as new
+        no_dense_work = (int32_t)(seen - c->reset_seq) >= 1 && (int32_t)(seen - c->cam_seq) >= 1 && c->h_fb[0] == 0 && c->h_fb[2] == 0;
+    }
     CellGrid cg = cell_grid(c);
     cg.dense_is_sorted = expect_dense ? 1 : 0;
     cg.frame_seq = ++c->frame_seq;
@@ -671,17 +682,18 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
             return fail(c, VRT_HIP_ERR_INVALID, "frame batch: table mode and two waves per block are not batched");
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
         if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
+        if (no_dense_work) dense_grid = 0;
         FrameArgs &fa = *c->defer;
         fa.S = tables(c); fa.T = t; fa.C = cg; fa.R = ray_gen(c, origin); fa.O = o;
-        c->deferred.render = true; c->deferred.render_grid = grid; c->deferred.order = expect_dense; c->deferred.dense_grid = dense_grid;
+        c->deferred.render = true; c->deferred.render_grid = grid; c->deferred.order = expect_dense && !no_dense_work; c->deferred.dense_grid = dense_grid;
         return VRT_HIP_OK;
     }
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
     launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->render_nw, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
     // dense queue: 16-wave workgroups pull blocks until the queue is empty (they exit at once if it is)
-    if (expect_dense) launch_order_dense(cg, st);
-    {
+    if (expect_dense && !no_dense_work) launch_order_dense(cg, st);
+    if (!no_dense_work) {
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
         if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
         if (c->table_hx > 0.f) {
@@ -763,6 +775,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     }
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
     if (const char *e = getenv("VRT_HIP_TILE_CONES")) c->cache_cones = atoi(e) != 0;
+    if (const char *e = getenv("VRT_HIP_DENSE_SKIP")) c->skip_idle_dense = atoi(e) != 0;
     if (const char *e = getenv("VRT_HIP_DENSE_IDLE_GRID")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 256) c->dense_idle_grid = v;

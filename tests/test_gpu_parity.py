@@ -658,6 +658,72 @@ def test_frames_enqueued_back_to_back_with_a_moving_camera(pkg, oracle, renderer
     assert dense_seen      # the orbit does pass through views that need the dense kernel
 
 
+def test_dense_launch_is_left_out_only_while_nothing_changed(pkg, oracle, renderer):
+    """Once a frame has REPORTED that it had no dense cell and no handed-over block, later frames of the same scene, options,
+    rays and camera launch no dense kernel at all (the report is exact for them).  The first frame after any change must
+    bring it back: here the context is driven into that state (frames waited for, so the reports are in), then the camera
+    turns to a view with dense cells / the scene becomes a dense one / the cull threshold changes -- every frame equals
+    the frame of a fresh context."""
+    import torch
+    from sgrt_amd import scene
+    w = h = 2048                       # `-g 64` has no dense cell at this size seen straight on, and has some at 47 degrees
+    grid = scene.grid_scene(64)
+    monkey = scene.read_obj(os.path.join(GOLDEN, "test-objects", "monkey.obj"))
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    st = torch.cuda.current_stream().cuda_stream
+    cam0 = scene.cli_camera(w, h)[0]
+    cam47 = scene.cli_camera(w, h, initial_rot=47.0)[0]
+
+    def fresh(g, cam, eps=1e-9):
+        renderer.set_gaussians(g)
+        renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps)
+        renderer.set_camera_view(w, h, cam.view)
+        renderer.tile_gaussians(2 / 16, 2 / 16, cam.view)
+        renderer.enable_stats(True)
+        img, _ = renderer.render(cam.position, pack, want_radiance=False)
+        dense = renderer.stats()["dense_blocks"]
+        renderer.enable_stats(False)
+        return img.reshape(-1), dense
+
+    r = pkg.Renderer(0)
+    buf = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    try:
+        def settle(g, cam, eps=1e-9, n=6):
+            r.set_gaussians(g)
+            r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps)
+            r.set_camera_view(w, h, cam.view)
+            for _ in range(n):
+                r.frame_call(2 / 16, 2 / 16, cam.view, cam.position, pack)(buf.data_ptr(), st)
+                torch.cuda.synchronize()
+
+        def frame(cam):
+            r.set_camera_view(w, h, cam.view)
+            r.frame_call(2 / 16, 2 / 16, cam.view, cam.position, pack)(buf.data_ptr(), st)
+            torch.cuda.synchronize()
+            return buf.cpu().numpy().view(np.uint32)
+
+        want0, d0 = fresh(grid, cam0)
+        want47, d47 = fresh(grid, cam47)
+        assert d0 == 0 and d47 > 0
+        settle(grid, cam0)
+        np.testing.assert_array_equal(frame(cam0), want0)
+        np.testing.assert_array_equal(frame(cam47), want47)          # the camera turned: dense cells
+        np.testing.assert_array_equal(frame(cam47), want47)
+        np.testing.assert_array_equal(frame(cam0), want0)
+        settle(grid, cam0)
+        wantm, dm = fresh(monkey, cam0)
+        assert dm > 0
+        r.set_gaussians(monkey)                                       # another scene behind the same camera
+        np.testing.assert_array_equal(frame(cam0), wantm)
+        settle(grid, cam0)
+        want_e, _ = fresh(grid, cam0, eps=0.0)
+        r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 0.0)                   # other options
+        np.testing.assert_array_equal(frame(cam0), want_e)
+        renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    finally:
+        r.close()
+
+
 def test_frames_on_the_context_stream_then_on_a_caller_stream(pkg, oracle, renderer):
     """vrt_hip_frame without waiting (the CLI's animation loop: frames in flight on the context's own stream) followed at
     once by a frame of another camera on a caller's stream: the library orders the two itself (lists and queue counters of
