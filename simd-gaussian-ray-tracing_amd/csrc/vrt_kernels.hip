@@ -690,10 +690,11 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         }
         __syncthreads();
         if (!fast) {
-            // Per-ray lists that outgrow LDS: the block goes to the 16-waves-per-block kernel, which ALWAYS runs after
-            // this one.  Which kernel shades a block is a function of the block alone (the two kernels sum in different
-            // orders), so the image does not depend on launch heuristics: the host only chooses how LARGE the dense
-            // launch is (vrt_hip_api.cpp, render_common).
+            // Per-ray lists that outgrow LDS: the block goes to the 16-waves-per-block kernel, which runs after this one
+            // (the host leaves that launch out only when a frame of exactly this state has reported that nothing is
+            // handed over and no cell is dense).  Which kernel shades a block is a function of the block alone (the two
+            // kernels sum in different orders), so the image does not depend on launch heuristics: the host only
+            // chooses how LARGE the dense launch is (vrt_hip_api.cpp, render_common).
             if (first) C.overflow[atomicAdd(C.n_overflow, 1u)] = (cell << 4) | bi;
             continue;
         }
