@@ -102,6 +102,9 @@ struct vrt_hip_ctx {
     std::string cone_key;
     uint32_t plane_gen = 0;
     bool cache_cones = true;
+    // cells with at most this many candidates are shaded last (CellGrid::light_threshold; VRT_HIP_LIGHT_CELLS, 0 = off);
+    // lists_light: what the lists now in the buffers were built with (0 for sparse shards and the two-kernel list path)
+    uint32_t light_cells = 24, lists_light = 0;
     bool skip_idle_dense = true; // VRT_HIP_DENSE_SKIP=0: the dense kernel is launched behind every block kernel
     float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
@@ -371,6 +374,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.count = c->c_count.p; g.indices = c->c_indices.p; g.active = c->c_active.p; g.n_cells = c->n_cells;
     g.dense = c->c_dense.p; g.dense_sorted = c->c_dense_sorted.p; g.scratch = c->c_scratch.p; g.slot = c->c_slot.p;
     g.n_active = cnt; g.n_dense = cnt + 2;
+    g.n_light = cnt + 1; g.light_threshold = c->lists_light; // as the lists in the buffers were built
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
     g.table_hx = c->table_hx; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
@@ -448,6 +452,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     const bool device_bin = c->tile_mode == TILES_DEVICE;
     // one fused kernel when a tile's cells fit one workgroup's waves; otherwise tile kernel + one-wave-per-cell kernel
     const bool fuse = c->cells_x * c->cells_y <= (uint32_t)MAX_FUSED_CELLS && (device_bin || refine);
+    c->lists_light = (fuse && !(target && target->sparse)) ? c->light_cells : 0u;
     FuseArgs f{};
     f.enabled = fuse ? 1 : 0;
     f.tile_map = fuse ? tile_map : nullptr;
@@ -775,6 +780,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     }
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
     if (const char *e = getenv("VRT_HIP_TILE_CONES")) c->cache_cones = atoi(e) != 0;
+    if (const char *e = getenv("VRT_HIP_LIGHT_CELLS")) c->light_cells = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("VRT_HIP_DENSE_SKIP")) c->skip_idle_dense = atoi(e) != 0;
     if (const char *e = getenv("VRT_HIP_DENSE_IDLE_GRID")) {
         const int v = atoi(e);

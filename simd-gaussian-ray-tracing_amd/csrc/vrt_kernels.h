@@ -67,6 +67,12 @@ struct CellGrid {
     uint32_t *slot;                  // [cells] position of a non-empty cell in its queue (bit 31: the dense queue): its place in
                                      // a sparse shard (RenderTarget::sparse) -- written by the list kernels
     uint32_t *n_active, *n_dense;    // device counters, zeroed before the list kernels add to them
+    // Cells with short lists ("light": at most light_threshold candidates -- the rim of what the scene covers) are filed from
+    // the BACK of `active` (n_light of them: active[n_cells - 1 - k]) and shaded last: a frame rarely has a multiple of the
+    // GPU's wave slots in blocks, and the blocks that run as a fourth wave on their SIMD should be the cheap ones.
+    // Raster frames only: a sparse shard needs its cells in one contiguous run of slots (light_threshold = 0 there).
+    uint32_t *n_light;
+    uint32_t light_threshold;
     uint32_t *dense_next;            // work counter of the dense kernel (zeroed with the others)
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
                                      // LDS slots: it hands them to the dense kernel, which runs after it

@@ -543,7 +543,8 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     if (C.feedback && wave == 0 && first) {
         __hip_atomic_store(&C.feedback[0], n_dense_cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const uint32_t n_shade = n_active * 16u; // the dense cells belong to the 16-waves-per-block kernel behind this one
+    const uint32_t n_light = C.light_threshold ? *C.n_light : 0u; // cells filed from the back of the queue: shaded last
+    const uint32_t n_shade = (n_active + n_light) * 16u; // the dense cells belong to the 16-waves-per-block kernel behind this one
     if (O.sparse_hdr && wave == 0 && first) { // sparse shard header; the counts are final: the list kernel is done
         O.sparse_hdr[0] = n_active + n_dense_cells; O.sparse_hdr[1] = O.sparse_cap;
         O.sparse_hdr[2] = C.cells_x * C.cells_y; O.sparse_hdr[3] = 0;
@@ -608,7 +609,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     for (uint32_t item = wave; item < n_shade; item = next_item()) {
         const unsigned long long tl0 = O.timeline ? wall_clock64() : 0ull; // diagnostics (VRT_HIP_TIMELINE runs only)
         const uint32_t ci = item >> 4;
-        const uint32_t cell = C.active[ci];
+        const uint32_t cell = C.active[ci < n_active ? ci : C.n_cells - 1u - (ci - n_active)];
         const uint32_t bi = item & 15u;
         const BlockPos p = block_of(T, C, O, cell, bi, lane);
         if (!p.inside) continue;
@@ -1620,7 +1621,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         }
         if (lane == 0) {
             C.count[cell] = ctotal;
-            s_flag[ci] = ctotal ? (ctotal > C.dense_threshold ? 3u : 1u) : 0u;
+            s_flag[ci] = ctotal ? (ctotal > C.dense_threshold ? 3u : (ctotal <= C.light_threshold ? 5u : 1u)) : 0u;
         }
     }
     __syncthreads();
@@ -1628,15 +1629,18 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     if (wave == 0) { // cpt <= 64: one flag per lane
         const uint32_t mine = lane < cpt ? s_flag[lane] : 2u;
         const unsigned long long m_act = __ballot(mine == 1u), m_dense = __ballot(mine == 3u), m_empty = __ballot(mine == 0u);
-        const uint32_t na = (uint32_t)__popcll(m_act), nd = (uint32_t)__popcll(m_dense);
+        const unsigned long long m_light = __ballot(mine == 5u);
+        const uint32_t na = (uint32_t)__popcll(m_act), nd = (uint32_t)__popcll(m_dense), nl = (uint32_t)__popcll(m_light);
         // empty cells are not queued (count == 0 says it): most tiles of a sparse frame then add to no counter at all
-        uint32_t base_a = 0, base_d = 0;
+        uint32_t base_a = 0, base_d = 0, base_l = 0;
         if (lane == 0) {
             if (na) base_a = atomicAdd(C.n_active, na);
             if (nd) base_d = atomicAdd(C.n_dense, nd);
+            if (nl) base_l = atomicAdd(C.n_light, nl);
             s_base[3] = (uint32_t)__popcll(m_empty);
         }
         base_a = (uint32_t)__shfl((int)base_a, 0, 64); base_d = (uint32_t)__shfl((int)base_d, 0, 64);
+        base_l = (uint32_t)__shfl((int)base_l, 0, 64);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t cell = lt * cpt + lane;
         if (mine == 1u) {
@@ -1644,6 +1648,8 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
             C.active[pos] = cell;
             if (C.slot) C.slot[cell] = pos;
             if (F.O.sparse) F.O.keys[pos] = t * cpt + lane;
+        } else if (mine == 5u) { // light: from the back of the active queue (raster frames only: no slot, no key)
+            C.active[C.n_cells - 1u - (base_l + (uint32_t)__popcll(m_light & below))] = cell;
         } else if (mine == 3u) {
             const uint32_t pos = base_d + (uint32_t)__popcll(m_dense & below);
             C.dense[pos] = cell;
