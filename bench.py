@@ -420,14 +420,14 @@ def main():
     kt = r.kernel_timing()
     r.enable_kernel_timing(False)
     # after the timed region: strictly serial frames on one context (no events), then the per-kernel breakdown
-    n_serial = min(args.steps, 400)
+    n_serial = max(200, min(args.steps, 400))   # its own sample size: a 20-step timed region says little about one frame's latency
     barrier()
     t1 = time.perf_counter()
     run(n_serial, 1, serial=True)
     barrier()
     serial_ms = (time.perf_counter() - t1) / max(n_serial, 1) * 1e3
     r.enable_kernel_timing(1)
-    run(min(args.steps, 100), 1, serial=True)
+    run(max(50, min(args.steps, 100)), 1, serial=True)
     barrier()
     seq = r.kernel_timing()
     r.enable_kernel_timing(False)
