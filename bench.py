@@ -197,8 +197,10 @@ def main():
     ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
     ap.add_argument("--setup-ms", type=float, default=50.0, help="untimed set-up frames before the warm-up steps, in milliseconds of wall time")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: launch every frame of a gather batch on its own (round-2 baseline)")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
-                    help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial frames")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial "
+                         "frames; 0 (default) = 4, or 3 when fewer than 32 steps are timed (a short run is mostly filling and "
+                         "draining the pipeline: 20 steps read 30.4-31.0 us per frame with three in flight, 31.6-34.6 with four)")
     ap.add_argument("--parallel", choices=["tiles", "frames"], default="tiles",
                     help="N > 1: 'tiles' = one frame's tiles sharded over the ranks + gather (the headline, SURVEY 8e); 'frames' = "
                          "every rank renders whole frames of its own, no collective (the replicas-only alternative: weak scaling)")
@@ -252,6 +254,8 @@ def main():
     # measured after the timed region and reported next to the headline ("serial").  N > 1: one context per rank
     # (the frame rate is set by the gather there).
     solo = world == 1 or args.parallel == "frames"   # this rank renders whole frames on its own
+    if args.frames_in_flight <= 0:
+        args.frames_in_flight = 4 if args.steps >= 32 else 3
     nctx = max(1, args.frames_in_flight) if solo else 1
 
     def make_renderer():
