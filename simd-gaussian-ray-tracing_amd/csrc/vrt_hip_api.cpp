@@ -442,12 +442,16 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         const uint32_t geo_key[6] = { geo.tile_w, geo.tile_h, geo.stride, geo.tiles_w, geo.tiles_h, c->plane_gen };
         key.append((const char *)geo_key, sizeof geo_key);
         a.tiles_w = geo.tiles_w;
-        if (key != c->cone_key || c->tile_cones.cap < 2 * nt) {
-            HIPCHK(c, c->tile_cones.reserve(2 * nt));
-            launch_tile_cones(a, geo.tiles_h, c->tile_cones.p, st);
+        // with the cells' cones when the tile's cells are filtered by the same workgroup (the fused list kernel)
+        const uint32_t cpt = c->cells_x * c->cells_y;
+        const uint32_t cones_cells = cpt <= (uint32_t)MAX_FUSED_CELLS ? cpt : 0u;
+        const size_t rows = nt * (1 + cones_cells);
+        if (key != c->cone_key || c->tile_cones.cap < 2 * rows) {
+            HIPCHK(c, c->tile_cones.reserve(2 * rows));
+            launch_tile_cones(a, geo.tiles_h, cones_cells ? c->cells_x : 0u, cones_cells ? c->cells_y : 0u, c->tile_cones.p, st);
             c->cone_key = key;
         }
-        a.tile_cones = c->tile_cones.p;
+        a.tile_cones = c->tile_cones.p; a.cones_cells = cones_cells;
     }
     const bool device_bin = c->tile_mode == TILES_DEVICE;
     // one fused kernel when a tile's cells fit one workgroup's waves; otherwise tile kernel + one-wave-per-cell kernel

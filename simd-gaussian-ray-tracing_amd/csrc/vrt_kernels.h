@@ -170,10 +170,11 @@ struct BinArgs {
     const uint32_t *out_start;
     uint32_t *out_indices, *out_count;
     float cull_ref_n, floor_x;       // TileLists::cull_ref_n, floor_x
-    // nullable: the tile cones, two float4 per tile id (axis, cos | sin, -, -, -), made by launch_tile_cones for these rays
+    // nullable: the tile cones and their cells' cones, two float4 per cone (axis, cos | sin, -, -, -), made by launch_tile_cones for these rays
     // and this tile geometry -- they depend on the camera only, so a frame with the camera of the last one reuses them
     // (otherwise every wave of the workgroup builds the tile's cone itself)
     const float4 *tile_cones;
+    uint32_t cones_cells;            // cells per tile the table holds cones for (row of tile t: t * (1 + cones_cells); 0: tile cones only)
     uint32_t *zero8;                 // nullable: 8 queue counters this launch clears for the kernels after it
     uint32_t *next_zero8;            // nullable: the OTHER counter set, cleared for the next list generation
 };
@@ -187,7 +188,7 @@ struct FuseArgs {
     unsigned long long *timeline; // nullable diagnostics: 8 wall_clock64 stamps per tile workgroup
 };
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st);
-void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, float4 *cones_out, hipStream_t st);
+void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uint32_t cells_y, float4 *cones_out, hipStream_t st);
 
 // Several frames per launch (vrt_hip_frame_batch_device): what one frame's three kernels take, as a row of a device array;
 // the batch variants of the kernels are the same code with blockIdx.y choosing the row.  A frame of a sparse scene is a

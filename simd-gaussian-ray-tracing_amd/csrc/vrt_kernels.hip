@@ -1447,21 +1447,37 @@ __device__ __forceinline__ Cone tile_cone(const BinArgs &P, uint32_t tx, uint32_
     };
     return rect_cone(at, 0, 0, P.tile_w - 1, P.tile_h - 1, lane);
 }
-// one wave per tile id: the cones the list kernel would build per workgroup (16 waves each), once per camera
-__global__ __launch_bounds__(256) void tile_cones_kernel(BinArgs P, uint32_t n_tiles, float4 *out)
+// cone of cell ci of a tile (32x32 px, clipped to the tile), as the second level builds it
+__device__ __forceinline__ Cone cell_cone(const BinArgs &P, uint32_t tx, uint32_t ty, uint32_t ci, uint32_t cells_x, uint32_t lane)
 {
-    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (t >= n_tiles) return;
-    const Cone c = tile_cone(P, t % P.tiles_w, t / P.tiles_w, lane);
+    const uint64_t npix = (uint64_t)P.R.width * P.R.height;
+    const uint32_t x0 = (ci % cells_x) * CELL, y0 = (ci / cells_x) * CELL;
+    const uint32_t x1 = min(x0 + CELL, P.tile_w) - 1, y1 = min(y0 + CELL, P.tile_h) - 1;
+    auto at = [&](uint32_t x, uint32_t y) {
+        uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
+        if (pix >= npix) pix = npix - 1;
+        return cone_ray(P.R, pix);
+    };
+    return rect_cone(at, x0, y0, x1, y1, lane);
+}
+// One wave per cone: per tile id its own cone (slot 0) and the cones of its cells (slots 1 .. cells per tile) -- what the
+// list kernel would build per workgroup and frame, once per camera.  Row = two float4: (axis, cos), (sin, -, -, -).
+__global__ __launch_bounds__(256) void tile_cones_kernel(BinArgs P, uint32_t n_tiles, uint32_t cells_x, uint32_t cells_y, float4 *out)
+{
+    const uint32_t per = 1 + cells_x * cells_y;
+    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= n_tiles * per) return;
+    const uint32_t t = k / per, c = k % per;
+    const Cone cn = c ? cell_cone(P, t % P.tiles_w, t / P.tiles_w, c - 1, cells_x, lane) : tile_cone(P, t % P.tiles_w, t / P.tiles_w, lane);
     if (lane == 0) {
-        out[2 * t] = make_float4(c.cx, c.cy, c.cz, c.cos_t);
-        out[2 * t + 1] = make_float4(c.sin_t, 0.f, 0.f, 0.f);
+        out[2 * k] = make_float4(cn.cx, cn.cy, cn.cz, cn.cos_t);
+        out[2 * k + 1] = make_float4(cn.sin_t, 0.f, 0.f, 0.f);
     }
 }
-void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, float4 *cones_out, hipStream_t st)
+void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uint32_t cells_y, float4 *cones_out, hipStream_t st)
 {
-    const uint32_t n_tiles = a.tiles_w * tiles_h;
-    if (n_tiles) hipLaunchKernelGGL(tile_cones_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, a, n_tiles, cones_out);
+    const uint32_t n = a.tiles_w * tiles_h * (1 + cells_x * cells_y);
+    if (n) hipLaunchKernelGGL(tile_cones_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a, a.tiles_w * tiles_h, cells_x, cells_y, cones_out);
 }
 
 template <bool FROM_LIST>
@@ -1517,7 +1533,8 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     Cone cone = {};
     if (P.refine) {
         if (P.tile_cones) { // made once for this camera (tile_cones_kernel)
-            const float4 c0 = P.tile_cones[2 * t], c1 = P.tile_cones[2 * t + 1];
+            const size_t row = (size_t)t * (1 + P.cones_cells);
+            const float4 c0 = P.tile_cones[2 * row], c1 = P.tile_cones[2 * row + 1];
             cone.cx = c0.x; cone.cy = c0.y; cone.cz = c0.z; cone.cos_t = c0.w; cone.sin_t = c1.x;
         } else {
             cone = tile_cone(P, tx, ty, lane);
@@ -1588,20 +1605,19 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     const uint64_t npix = (uint64_t)P.R.width * P.R.height;
     for (uint32_t ci = wave; ci < cpt; ci += 16) {
         const uint32_t cell = lt * cpt + ci;
-        const uint32_t x0 = (ci % C.cells_x) * CELL, y0 = (ci / C.cells_x) * CELL;
-        const uint32_t x1 = min(x0 + CELL, P.tile_w) - 1, y1 = min(y0 + CELL, P.tile_h) - 1;
         uint32_t ctotal = 0;
         if (total > TCAP) {
             ctotal = 0xFFFFFFFFu; // the tile's list did not fit LDS: its cells use the tile list itself
         } else if (total) {
             Cone cc = {};
             if (P.refine) {
-                auto at = [&](uint32_t x, uint32_t y) {
-                    uint64_t pix = (uint64_t)(tx * P.tile_w + x) + (uint64_t)P.stride * (ty * P.tile_h + y);
-                    if (pix >= npix) pix = npix - 1;
-                    return cone_ray(P.R, pix);
-                };
-                cc = rect_cone(at, x0, y0, x1, y1, lane);
+                if (P.tile_cones && P.cones_cells == cpt) {
+                    const size_t row = (size_t)t * (1 + cpt) + 1 + ci;
+                    const float4 c0 = P.tile_cones[2 * row], c1 = P.tile_cones[2 * row + 1];
+                    cc.cx = c0.x; cc.cy = c0.y; cc.cz = c0.z; cc.cos_t = c0.w; cc.sin_t = c1.x;
+                } else {
+                    cc = cell_cone(P, tx, ty, ci, C.cells_x, lane);
+                }
             }
             uint32_t *cout = C.indices + (size_t)cell * C.cstride;
             for (uint32_t base = 0; base < total; base += 64) {
