@@ -1,0 +1,45 @@
+"""bench.py's contract on one GPU: ONE JSON line with the driver's keys, `value` = rays of exactly K timed steps over their
+wall time, the roofline and CPU-baseline objects, every frame buffer of the timed loop equal to a reference render."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("steps,in_flight", [(20, 3), (40, 4)])
+def test_bench_line(tmp_path, steps, in_flight):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "3", "--setup-ms", "5"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{")                   # one line, nothing else on stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == 3 and d["higher_is_better"] is True
+    assert d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "2048" in d["metric"] and "64x64" in d["metric"]
+    cfg = d["config"]
+    assert "workload" in cfg and "-g 64 -w 2048" in cfg["workload"] and "model" not in cfg
+    assert cfg["frames_in_flight"] == in_flight and cfg["frame_equals_single_gpu_frame"] is True
+    # value is whole-job throughput of the timed steps: rays per step / time per step
+    assert abs(d["value"] - 2048 * 2048 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
+    assert 10e-3 < d["ms_per_step"] < 80e-3 and 20e-3 < d["ms_per_frame"] < 100e-3
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    v = d["valu"]
+    assert 0 < v["algorithmic"]["frac_of_frame_time"] < 1
