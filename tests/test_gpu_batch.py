@@ -131,6 +131,43 @@ def test_batch_of_sparse_shards(pkg, renderer, name, w, tiles_n, world, rank):
             r.close()
 
 
+def test_batch_of_compact_shards(pkg, renderer):
+    """out_kind 1: rank 1 of 3's compact shard [slot][tile_h][tile_w] for n frames in one batch == vrt_hip_frame_device(..,
+    shard = 1) frame by frame."""
+    import torch
+    from sgrt_amd import scene
+    g = scene.grid_scene(16)
+    w, tiles_n, n = 512, 8, 3
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    cams = [scene.cli_camera(w, w, initial_rot=17.0 * i)[0] for i in range(n)]
+    tw = th = 2.0 / tiles_n
+    st = torch.cuda.current_stream().cuda_stream
+    ctxs = make_contexts(pkg, n + 1, g, w, w, cams[0], shard=(1, 3))
+    try:
+        single = ctxs[n]
+        single.tile_gaussians_device(tw, th, cams[0].view, st)
+        px = single.shard_pixels()
+        assert px > 0
+        want = []
+        for c in cams:
+            single.set_camera_view(w, w, c.view)
+            buf = torch.full((px,), 0x44, dtype=torch.int32, device="cuda")
+            single.frame_call(tw, th, c.view, c.position, pack, shard=True)(buf.data_ptr(), st)
+            torch.cuda.synchronize()
+            want.append(buf.cpu().numpy())
+        for r, c in zip(ctxs[:n], cams):
+            r.set_camera_view(w, w, c.view)
+        bufs = [torch.full((px,), 0x44, dtype=torch.int32, device="cuda") for _ in range(n)]
+        ctxs[0].frame_batch_call(ctxs[1:n], tw, th, [c.view for c in cams], [c.position for c in cams], pack, out_kind=1)([b.data_ptr() for b in bufs], st)
+        torch.cuda.synchronize()
+        for i in range(n):
+            np.testing.assert_array_equal(bufs[i].cpu().numpy(), want[i], err_msg=f"frame {i}")
+        assert any(int((w_ != 0x44).sum()) > 0 and int((w_ & 0xFFFFFF).max()) > 0 for w_ in want)
+    finally:
+        for r in ctxs:
+            r.close()
+
+
 def test_batch_refusals(pkg, renderer):
     import torch
     from sgrt_amd import scene
