@@ -223,7 +223,7 @@ int vrt_hip_scatter_sparse_batch_device(vrt_hip_ctx *ctx, const uint32_t *const 
  * each of the three kernels of a frame is launched ONCE for all n frames (grid.y = frame).  A sparse frame is tens of
  * microseconds of dependent launches: a batch pays the launch gaps and the kernels' tails once, and a rank that owns an
  * eighth of the tiles still fills its GPU.  Everything is enqueued on hip_stream; errors are reported through ctxs[0].
- * Not batched (VRT_HIP_ERR_INVALID): table mode, tiles of more than 64 cells, plane arrays that are no pinhole bundle. */
+ * Not batched (VRT_HIP_ERR_INVALID): tiles of more than 64 cells, plane arrays that are no pinhole bundle. */
 int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float th, const float *views,
                                const float *origins, int pack_flags, uint32_t *const *d_out, int out_kind,
                                void *hip_stream);
@@ -269,12 +269,17 @@ int vrt_hip_density(vrt_hip_ctx *ctx, size_t npts, const float *pts, float *D_ou
 int vrt_hip_eval_erf(vrt_hip_ctx *ctx, int erf_kind, const float *x, size_t n, float *y);
 int vrt_hip_eval_exp(vrt_hip_ctx *ctx, int exp_kind, const float *x, size_t n, float *y);
 
-/* Opt-in approximation for dense scenes (NOT the reference's sum; inside its tolerance): blocks with many overlapping
- * Gaussians evaluate the transmittance exponent of a ray at 160 nodes along it and interpolate the 5 n sample points
- * (n * 160 erf terms per ray instead of 5 n^2).  `step` = largest allowed node spacing in units of sqrt2 * sigma
- * (0 = off, the default; 0.08 keeps the exponent within ~2e-5); blocks that 160 nodes cannot cover at that spacing
- * are shaded exactly.  See render_table_kernel in csrc/vrt_kernels.hip. */
+/* Table mode for dense scenes (ON by default; NOT the reference's summation order, but inside its tolerance by a bound the
+ * kernel checks per ray): blocks with many overlapping Gaussians evaluate the transmittance exponent of a ray at up to 384
+ * equidistant nodes along it and interpolate the 5 n sample points (n * G erf terms per ray instead of 5 n^2).
+ * `step` = requested node spacing in units of sqrt2 * sigma of the narrowest Gaussian of the block (default 0.05; 0 = off:
+ * the exact kernels only, which reproduce the reference's per-term sums).  Every ray's worst-case radiance change --
+ * sum over its samples of |term| * (0.0212 u^2 * K + 0.36 u^4 * S_all), see render_table_body in csrc/vrt_kernels.hip --
+ * must stay below the budget (default 2.5e-5), or the block is redone at 0.6 of the spacing and then shaded exactly; so
+ * are blocks with more than 512 survivors or a depth range the nodes cannot cover at 2.5 x the requested spacing.
+ * Applies to the Exp / Erf pairs {vcl_exp, expf} x {A&S erf, erff}; other pairs are always exact. */
 int vrt_hip_set_table_step(vrt_hip_ctx *ctx, float step);
+int vrt_hip_set_table_budget(vrt_hip_ctx *ctx, float budget);
 
 /* -------- statistics of the last render ----------------------------------------------------- */
 typedef struct {
@@ -298,6 +303,11 @@ typedef struct {
     uint64_t dense_visits_full;   /* evaluated term by term                                              */
     uint64_t dense_visits_zero;   /* every term exactly 0 (absorber behind all samples): skipped         */
     uint64_t dense_visits_common; /* every term exactly -2 A_j (absorber in front of all samples): one fma */
+    /* table kernel */
+    uint64_t table_nodes;     /* sum over its blocks of the node count G                                     */
+    uint64_t table_retries;   /* blocks that met the error budget only at the reduced spacing                */
+    uint64_t table_skips;     /* (absorber, wave) visits settled by saturation (one add instead of NT terms) */
+    uint64_t table_declined;  /* blocks handed to the exact kernel                                           */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

@@ -36,7 +36,8 @@ class Stats(C.Structure):
                 ("lane_entries", C.c_uint64), ("lane_max_entries", C.c_uint64), ("shaded_blocks", C.c_uint64), ("dense_blocks", C.c_uint64),
                 ("dense_busy_frac", C.c_double), ("table_blocks", C.c_uint64),
                 ("lane_pairs", C.c_uint64), ("dense_visits_full", C.c_uint64), ("dense_visits_zero", C.c_uint64),
-                ("dense_visits_common", C.c_uint64)]
+                ("dense_visits_common", C.c_uint64), ("table_nodes", C.c_uint64), ("table_retries", C.c_uint64),
+                ("table_skips", C.c_uint64), ("table_declined", C.c_uint64)]
 
 
 def build(verbose=False):
@@ -71,6 +72,7 @@ SYMBOLS = {
     "vrt_hip_shard_pixels": (C.c_size_t, [_vp]),
     "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
     "vrt_hip_set_table_step": (C.c_int, [_vp, C.c_float]),
+    "vrt_hip_set_table_budget": (C.c_int, [_vp, C.c_float]),
     "vrt_hip_set_camera_view": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p]),
     "vrt_hip_frame": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, C.c_int]),
     "vrt_hip_sync": (C.c_int, [_vp]),
@@ -412,8 +414,12 @@ class Renderer:
         self._chk(self._L.vrt_hip_enable_stats(self._h, int(on)), "enable_stats")
 
     def set_table_step(self, step):
-        """Opt-in table mode for dense blocks (0 = off): see vrt_hip_set_table_step in include/vrt_hip.h."""
+        """Table mode for dense blocks (default 0.05; 0 = exact kernels only): see vrt_hip_set_table_step in include/vrt_hip.h."""
         self._chk(self._L.vrt_hip_set_table_step(self._h, float(step)), "set_table_step")
+
+    def set_table_budget(self, budget):
+        """Largest worst-case change of a ray's radiance the table kernel may cause (default 2.5e-5)."""
+        self._chk(self._L.vrt_hip_set_table_budget(self._h, float(budget)), "set_table_budget")
 
     def enable_kernel_timing(self, on=True):
         self._chk(self._L.vrt_hip_enable_kernel_timing(self._h, int(on)), "enable_kernel_timing")

@@ -127,7 +127,8 @@ struct vrt_hip_ctx {
     // the GPU, not one frame on one workgroup.
     uint32_t frame_seq = 0, reset_seq = 0, cam_seq = 0;
     int num_cus = 256;
-    float table_hx = 0.f;  // vrt_hip_set_table_step(): 0 = the exact kernels only
+    float table_hx = 0.05f;      // vrt_hip_set_table_step(): requested node spacing of the table kernel; 0 = the exact kernels only
+    float table_budget = 2.5e-5f; // vrt_hip_set_table_budget(): worst-case change of a ray's radiance the table kernel may cause
     int dense_idle_grid = 1; // workgroups of the dense launch when nothing is expected for it (VRT_HIP_DENSE_IDLE_GRID): one
                              // 1024-thread workgroup finds a CU with 61 KB of LDS free sooner than eight do (-2 % with frames in flight)
     int dense_waves = 16; // waves per block in the dense kernel (tuning knob: VRT_HIP_DENSE_WAVES = 4 | 8 | 16)
@@ -217,6 +218,13 @@ float exp_floor_x(int exp_kind)
     case VRT_EXP_SPLINE: return 9.0f; // spline_exp(x) = 0 for x <= -9 (approx.cpp:143)
     default: return INFINITY;
     }
+}
+
+// table mode applies to the Exp / Erf pairs its error bound covers (vrt_kernels.hip, VRT_DISPATCH_TABLE)
+bool table_on(const vrt_hip_ctx *c)
+{
+    return c->table_hx > 0.f && (c->erf_kind == VRT_ERF_AS || c->erf_kind == VRT_ERF_LIBM) &&
+           (c->exp_kind == VRT_EXP_VCL || c->exp_kind == VRT_EXP_LIBM);
 }
 
 int rebuild_tables(vrt_hip_ctx *c)
@@ -319,6 +327,9 @@ int prepare_tile_grid(vrt_hip_ctx *c, float tw, float th)
     HIPCHK(c, hipMemcpy(c->w_start.p, start.data(), nt * 4, hipMemcpyHostToDevice));
     c->grid_tw = tw; c->grid_th = th; c->grid_n = c->n;
     if (c->tile_mode != TILES_DEVICE || c->tiles_w != tiles_w || c->tiles_h != tiles_h) c->shard_dirty = true;
+    // another tile grid = other cell lists, other cells beyond dense_threshold: launch reports of the old grid say nothing
+    // about this one (round-2 advisor finding: the dense launch was left out on the first frame of a new grid)
+    c->reset_seq = c->frame_seq;
     c->tile_mode = TILES_DEVICE; c->tw = tw; c->th = th; c->tiles_w = tiles_w; c->tiles_h = tiles_h;
     return VRT_HIP_OK;
 }
@@ -377,7 +388,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.n_light = cnt + 1; g.light_threshold = c->lists_light; // as the lists in the buffers were built
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
-    g.table_hx = c->table_hx; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
+    g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
     g.feedback = c->d_fb;
     g.dense_is_sorted = 1;
@@ -414,7 +425,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     HIPCHK(c, c->c_slot.reserve(c->n_cells));
     HIPCHK(c, c->c_scratch.reserve((size_t)c->num_cus * 4 * c->cstride)); // one slot per dense workgroup (<= 4 per CU)
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
-    if (c->table_hx > 0.f) HIPCHK(c, c->c_overflow2.reserve((size_t)c->n_cells * 16));
+    if (table_on(c)) HIPCHK(c, c->c_overflow2.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
     if (!c->c_counters.p) {
         HIPCHK(c, c->c_counters.reserve(16));
@@ -632,7 +643,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
     const TileLists t = work_lists(c);
     if (o.stats) {
-        HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 16 * sizeof(unsigned long long), st));
+        HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 24 * sizeof(unsigned long long), st));
         HIPCHK(c, hipMemsetAsync(c->d_stats.p + 8, 0xFF, sizeof(unsigned long long), st)); // running minimum
     }
     c->timeline_items = 0;
@@ -687,13 +698,18 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     cg.rq_next = c->c_rq.p + ((c->rq_gen + 1) & 1) * RQ_N * RQ_STRIDE;
     if (c->defer) {
         // a frame of a batch: the launches are made once for all frames by vrt_hip_frame_batch_device
-        if (c->table_hx > 0.f || c->render_nw != 1)
-            return fail(c, VRT_HIP_ERR_INVALID, "frame batch: table mode and two waves per block are not batched");
+        if (c->render_nw != 1) return fail(c, VRT_HIP_ERR_INVALID, "frame batch: two waves per block are not batched");
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
         if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
         if (no_dense_work) dense_grid = 0;
         FrameArgs &fa = *c->defer;
         fa.S = tables(c); fa.T = t; fa.C = cg; fa.R = ray_gen(c, origin); fa.O = o;
+        fa.C2 = cg;
+        if (table_on(c)) { // the exact kernel behind the table kernel works off the queue of declined blocks (as below)
+            uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
+            fa.C2.n_dense = cnt + 7; fa.C2.n_overflow = cnt + 5; fa.C2.overflow = c->c_overflow2.p; fa.C2.dense_next = cnt + 6;
+            fa.C2.feedback = nullptr;
+        }
         c->deferred.render = true; c->deferred.render_grid = grid; c->deferred.order = expect_dense && !no_dense_work; c->deferred.dense_grid = dense_grid;
         return VRT_HIP_OK;
     }
@@ -705,8 +721,8 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if (!no_dense_work) {
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
         if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
-        if (c->table_hx > 0.f) {
-            // opt-in table mode: the table kernel takes the whole dense queue and hands what it declines to a second
+        if (table_on(c)) {
+            // table mode (the default): the table kernel takes the whole dense queue and hands what it declines to a second
             // queue, which the exact kernel then works off (n_dense reads the always-zero word of the counter set)
             launch_render_table(tables(c), t, cg, ray_gen(c, origin), o, std::min<uint32_t>(dense_grid, (uint32_t)c->num_cus), c->exp_kind, c->erf_kind, st);
             CellGrid cq = cg;
@@ -783,6 +799,8 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
     }
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
+    if (const char *e = getenv("VRT_HIP_TABLE_STEP")) { const float v = (float)atof(e); if (v >= 0.f && v <= 1.f) c->table_hx = v; }
+    if (const char *e = getenv("VRT_HIP_TABLE_BUDGET")) { const float v = (float)atof(e); if (v > 0.f) c->table_budget = v; }
     if (const char *e = getenv("VRT_HIP_TILE_CONES")) c->cache_cones = atoi(e) != 0;
     if (const char *e = getenv("VRT_HIP_LIGHT_CELLS")) c->light_cells = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("VRT_HIP_DENSE_SKIP")) c->skip_idle_dense = atoi(e) != 0;
@@ -800,7 +818,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        c->d_stats.reserve(16) != hipSuccess) {
+        c->d_stats.reserve(24) != hipSuccess) {
         delete c;
         return fail(nullptr, VRT_HIP_ERR_HIP, "create: stream/event creation failed");
     }
@@ -903,6 +921,15 @@ int vrt_hip_set_table_step(vrt_hip_ctx *c, float hx)
     if (!(hx >= 0.f) || hx > 1.f) return fail(c, VRT_HIP_ERR_INVALID, "set_table_step: step must be in [0, 1]");
     if (hx != c->table_hx) { c->reset_seq = c->frame_seq; c->lists_dirty = true; }
     c->table_hx = hx;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_table_budget(vrt_hip_ctx *c, float budget)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!(budget > 0.f)) return fail(c, VRT_HIP_ERR_INVALID, "set_table_budget: the budget must be positive (INFINITY = unchecked)");
+    if (budget != c->table_budget) c->reset_seq = c->frame_seq;
+    c->table_budget = budget;
     return VRT_HIP_OK;
 }
 
@@ -1138,8 +1165,9 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
     if (c->stats_on) {
-        unsigned long long st[16];
+        unsigned long long st[24];
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
+        c->last.table_nodes = st[16]; c->last.table_retries = st[17]; c->last.table_skips = st[18]; c->last.table_declined = st[19];
         c->last.lane_pairs = st[12];
         c->last.dense_visits_full = st[13]; c->last.dense_visits_zero = st[14]; c->last.dense_visits_common = st[15];
         c->last.dense_busy_frac = (st[11] && st[9] > st[8]) ? (double)st[10] / ((double)st[11] * (double)(st[9] - st[8])) : 0.0;
@@ -1329,8 +1357,9 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
         if (!c || !d_out[i]) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: null context or output");
         for (int k = 0; k < i; ++k)
             if (ctxs[k] == c) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: a context holds ONE frame's lists and queues -- every frame of a batch needs its own");
-        if (c->device != c0->device || c->exp_kind != c0->exp_kind || c->erf_kind != c0->erf_kind || c->dense_waves != c0->dense_waves)
-            return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the contexts differ in device or in Exp / Erf / dense-kernel options");
+        if (c->device != c0->device || c->exp_kind != c0->exp_kind || c->erf_kind != c0->erf_kind || c->dense_waves != c0->dense_waves ||
+            c->table_hx != c0->table_hx || c->table_budget != c0->table_budget)
+            return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the contexts differ in device or in Exp / Erf / dense-kernel / table options");
         if (c->w != c0->w || c->h != c0->h || c->n != c0->n || c->rank != c0->rank || c->world != c0->world)
             return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the frames differ in image size, scene size or shard");
         if (out_kind == OUT_SPARSE && (uintptr_t)d_out[i] % 16) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: sparse shard buffers must be 16-byte aligned");
@@ -1400,7 +1429,10 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
         if (ctxs[i]->deferred.order) launch_order_dense(rows[i].C, st);
         dgrid = std::max(dgrid, ctxs[i]->deferred.dense_grid);
     }
-    launch_render_dense_batch(d_rows, (uint32_t)n, dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
+    if (table_on(c0))
+        launch_render_table_batch(d_rows, (uint32_t)n, std::min<uint32_t>(dgrid, (uint32_t)c0->num_cus), dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
+    else
+        launch_render_dense_batch(d_rows, (uint32_t)n, dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
     HIPCHK(c0, hipGetLastError());
     return VRT_HIP_OK;
 }
@@ -1437,23 +1469,34 @@ int assembly_geometry(vrt_hip_ctx *c, int pack_flags, AssemblyGeometry &g)
 // frame: ~4 us of HBM writes, more than a rank's share of the rendering at 8 GPUs) shrink to the cells that were lit last
 // time and are not now (clear_stale_cells_kernel, after the scatter).  A new buffer, image size, tile grid or background
 // value gets the full fill and starts a new history.
+// `batch` / `nbatch`: the frame buffers of the call this one belongs to -- their histories' stamp buffers are already part of
+// the launch being prepared and must not be evicted to make room (round-2 advisor finding).
 int assembly_background(vrt_hip_ctx *c, const AssemblyGeometry &g, uint32_t *d_image, bool retained, hipStream_t st, uint32_t **stamp,
-                        uint32_t *seq, bool *incremental)
+                        uint32_t *seq, bool *incremental, uint32_t *const *batch = nullptr, int nbatch = 0)
 {
     *stamp = nullptr; *seq = 0; *incremental = false;
     auto it = std::find_if(c->retained.begin(), c->retained.end(), [&](const vrt_hip_ctx::Retained &r) { return r.image == d_image; });
     if (!retained) {
         if (it != c->retained.end()) { // a plain assembly into a retained buffer ends its history
-            HIPCHK(c, hipStreamSynchronize(st));
+            // its stamps may still be read by an earlier retained assembly on ANY stream: wait for the device
+            HIPCHK(c, hipDeviceSynchronize());
             it->stamp.release();
             c->retained.erase(it);
         }
     } else {
         if (it == c->retained.end()) {
             if (c->retained.size() >= (size_t)MAX_ASSEMBLY_FRAMES) {
-                HIPCHK(c, hipStreamSynchronize(st));
-                c->retained.front().stamp.release();
-                c->retained.erase(c->retained.begin());
+                // the oldest history that is not one of this call's own buffers (a call has at most MAX_ASSEMBLY_FRAMES
+                // distinct buffers and this one is new, so there is one); earlier assemblies of it may have run on another
+                // stream than `st`: wait for the device (a rare path: more than 64 frame buffers in rotation)
+                auto victim = std::find_if(c->retained.begin(), c->retained.end(), [&](const vrt_hip_ctx::Retained &r) {
+                    for (int k = 0; k < nbatch; ++k) if (batch[k] == r.image) return false;
+                    return true;
+                });
+                if (victim == c->retained.end()) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse: no retained history can be dropped");
+                HIPCHK(c, hipDeviceSynchronize());
+                victim->stamp.release();
+                c->retained.erase(victim);
             }
             c->retained.emplace_back();
             it = c->retained.end() - 1;
@@ -1528,7 +1571,7 @@ int vrt_hip_scatter_sparse_batch_device(vrt_hip_ctx *c, const uint32_t *const *d
         for (int k = 0; k < f; ++k)
             if (d_images[k] == d_images[f]) return fail(c, VRT_HIP_ERR_INVALID, "scatter_sparse_batch: two frames of a batch into one buffer");
         bool incremental;
-        if ((rc = assembly_background(c, g, d_images[f], retained != 0, st, &fr.stamp[f], &fr.seq[f], &incremental))) return rc;
+        if ((rc = assembly_background(c, g, d_images[f], retained != 0, st, &fr.stamp[f], &fr.seq[f], &incremental, d_images, nframes))) return rc;
         fr.image[f] = d_images[f];
         fr.clear[f] = incremental ? 1 : 0;
     }

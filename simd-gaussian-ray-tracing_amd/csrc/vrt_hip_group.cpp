@@ -147,6 +147,9 @@ int vrt_hip_group_frame(vrt_hip_group *g, float tw, float th, const float view[1
         if (!words) return gfail(g, VRT_HIP_ERR_INVALID, "group_frame: set the rays of every member first (vrt_hip_set_camera_view / set_plane)");
         if (words > mb.shard_words) {
             GCHK(g, hipStreamSynchronize(mb.stream));
+            // the previous frame's assembly on member 0's stream may still be reading this shard (peer access) or its
+            // staged copy: wait for it on the host before either is freed (round-2 advisor finding)
+            if (g->have_assembled) GCHK(g, hipEventSynchronize(g->assembled));
             if (mb.shard) (void)hipFree(mb.shard);
             mb.shard = nullptr; mb.shard_words = 0;
             GCHK(g, hipMalloc((void **)&mb.shard, words * sizeof(uint32_t)));

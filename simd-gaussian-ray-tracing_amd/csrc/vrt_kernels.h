@@ -89,9 +89,10 @@ struct CellGrid {
     // are pulled from RQ_N counters RQ_STRIDE words apart (item G + q + RQ_N*m is the m-th of queue q).  `rq` is this
     // launch's set (zero on entry), `rq_next` the other set, which this launch clears for the next one.
     uint32_t *rq, *rq_next;
-    // table mode (render_table_kernel): node spacing limit in units of 1/r (0 = off) and the queue of the blocks it
-    // declines, which the exact dense kernel works off afterwards
-    float table_hx;
+    // table mode (render_table_kernel): requested node spacing in units of 1/r (0 = off), the largest change of a ray's
+    // radiance the table may cause (worst-case bound, checked per ray), and the queue of the blocks it declines, which
+    // the exact dense kernel works off afterwards
+    float table_hx, table_budget;
     uint32_t *overflow2, *n_overflow2;
 };
 constexpr uint32_t RQ_N = 8, RQ_STRIDE = 64;
@@ -131,6 +132,8 @@ struct RenderTarget {
                                // [3]=sum of lane list lengths [4]=sum over blocks of the longest lane list [5]=shaded blocks
                                // [6]=dense blocks [7]=table blocks [8..11]=dense workgroup timeline [12]=sum over rays of (lane list length)^2
                                // [13..15]=dense kernel: (emitter chunk, absorber) visits evaluated in full / exactly zero / exactly -2A
+                               // [16]=table kernel: sum of node counts over its blocks [17]=blocks it did at the reduced spacing
+                               // [18]=(absorber, wave) visits it settled by saturation [19]=blocks it declined   (24 words in all)
     unsigned long long *timeline; // nullable diagnostics: 4 wall_clock64 stamps + the hardware id per one-wave work item (5 words)
 };
 
@@ -197,10 +200,13 @@ void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uin
 struct FrameArgs {
     BinArgs bin; FuseArgs fuse;                                   // list kernel
     SceneTables S; TileLists T; CellGrid C; RayGen R; RenderTarget O;   // one-wave kernel and dense kernel
+    CellGrid C2;                                                  // table mode: the exact kernel's view of the queue of declined blocks
 };
 void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, uint32_t ntiles, hipStream_t st);
 void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
 void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int dw, int exp_kind, int erf_kind,
+                               hipStream_t st);
+void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, int exp_kind, int erf_kind,
                                hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,
                      uint32_t world, uint64_t rank_stride, const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);

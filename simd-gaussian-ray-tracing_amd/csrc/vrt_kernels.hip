@@ -1033,35 +1033,115 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_batch_kernel(const Fr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Opt-in (vrt_hip_set_table_step): dense blocks through a per-ray TABLE of the transmittance exponent.
-// Along one ray  X(s) = sum_j A_j (E_j - Erf(s r_j - m_j))  is ONE function of s, and the radiance needs it at
-// 5 n points (five samples per emitter).  The exact kernel above evaluates every one of them term by term:
-// 5 n^2 erf terms per ray.  Here X is evaluated at G = 160 equidistant nodes of the ray's sample range (n G terms,
-// the 16 waves of the workgroup take ten nodes each) and the 5 n samples are read off by 4-point Lagrange
-// interpolation.  The A&S erf has a jump of 0.59 in its second derivative at 0, so the node spacing h decides the
-// error: with h * max_j r_j <= 0.08 (the default step) the exponent is off by <= ~2e-5 (numeric study: 2.9e-5 at
-// 0.1, 4.4e-6 at 0.05, for 240 Gaussians of A <= 0.06) -- inside the 1e-4 tolerance, but NOT the reference's sum:
-// hence opt-in.  Blocks that are not eligible (more than 512 survivors, or a sample range that 160 nodes cannot
-// cover at the requested spacing: small sigma, deep scenes) go to a second queue, which the exact kernel works
-// off afterwards.  Pays off when n >> G / 5 = 32: the monkey (sigma .15, ~240 survivors per block) 5x.
+// Table mode (default; vrt_hip_set_table_step(0) = the exact kernels only): dense blocks through a per-ray TABLE of the
+// transmittance exponent.  Along one ray  X(s) = sum_j A_j (E_j - Erf(s r_j - m_j))  is ONE function of s, and the radiance
+// needs it at 5 n points (five samples per emitter).  The exact kernel evaluates every one of them term by term: 5 n^2 erf
+// terms per ray.  Here X is evaluated at G equidistant nodes of the ray's sample range (n G terms) and the 5 n samples are
+// read off by 4-point Lagrange interpolation.
+//
+// Error control.  The Abramowitz-Stegun erf has a jump of 0.586 in its second derivative at 0 (it is an odd extension of a
+// rational function), so X has a kink at every mubar_j.  For a unit erf tabulated with node spacing u (in units of 1/r_j) the
+// 4-point interpolant is off by at most 0.0212 u^2 where the stencil contains the kink -- less, by a known factor w <= 1, depending
+// on where in the stencil it lies (TB_W0 below) -- and by at most 0.36 u^4 where it does not (tools/table_error_study.py, all phases,
+// u <= 0.3).  So for a sample s in node interval g
+//     |dX(s)| <= 0.0212 u^2 * K(g) + 0.36 u^4 * S_all,   K(g) = sum of w_j |A_j| over the kinks in intervals g-1 .. g+1,  S_all = sum_j |A_j|,
+// and a ray's radiance moves by at most  sum_ik |albedo_i|max * |term_ik| * |dX(s_ik)|  (term_ik = the emission sample).
+// The kernel accumulates exactly this sum per ray (K from a per-ray pass over the A_j, kept as one byte per node) and
+// keeps a block only if every ray stays below the budget (CellGrid::table_budget, default 2.5e-5: with the cull thresholds'
+// 2.5e-5 the frame's worst case is 5e-5, half the 1e-4 tolerance).  A block that fails is tried once more at 0.6 of the
+// spacing and then handed to the exact kernel (second queue), as are blocks with more than 2048 survivors or a sample range
+// of more than 8 x 376 nodes.  The bound is a worst case (every kink at its worst phase,
+// all errors aligned): measured deviations are 20-30 x smaller.
+//
+// Work split: 16 waves hold the same 64 rays (lane = ray).  Wave w owns the contiguous nodes [w NT, (w+1) NT): an absorber
+// whose erf is saturated (exactly -1 or +1, erf_saturation<>) over that whole range on all 64 rays costs one add.  The
+// per-(ray, absorber) set-up (A_j, m_j: a dot product, an Exp) is made ONCE per block, 16 absorbers at a time into LDS
+// (wave w stages absorber w of the chunk), instead of by every wave for its own nodes.
 // ---------------------------------------------------------------------------------------------
-template <int EXP, int ERF>
-__global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
-                                                               RenderTarget O)
-{
-    constexpr int DW = 16, TC = 512, G = 160, NPW = G / DW, EC = 4;
-    const ErfEval<ERF> erf;
-    struct Lds {
-        union {
-            struct { float4 A[TC], B[TC]; } rows; // 16 KB: the survivors' parameter rows, in list order ...
-            float4 L[DW][64];                    // ... and, once every wave is done with them, the partial radiances
-        };
-        uint32_t idx[TC];
-        float tab[G][64];                        // 40 KB: X at node g of lane l
+constexpr int TB_TC = 2048, TB_GMAX = 384, TB_CH = 16, TB_DW = 16;
+static_assert(TB_CH == TB_DW, "one staged absorber per wave and chunk");
+// Per-kink error bound of the 4-point interpolant, in units of u^2 |A_j| (tools/table_error_study.py verifies the constants
+// for u <= 0.3, all phases): a kink at offset theta in [0, 1) of its node interval moves the interpolant by at most
+//   TB_W0 min(1, 0.28 + 2.58 |theta - 1/2|) u^2 in that interval, TB_W0 theta^2 u^2 in the interval to its right,
+//   TB_W0 (1 - theta)^2 u^2 in the one to its left, and by at most TB_COUT u^4 anywhere else.
+constexpr float TB_W0 = 0.0212f, TB_COUT = 0.36f;
+struct TableLds {
+    uint32_t idx[TB_TC];                       //  8 KB: the block's survivors, in list order (their rows come from the tables by
+                                               //        wave-uniform loads: every pass below needs a row once per wave)
+    union {                                    // 96 KB: X at node g of lane l; before that the kink weights per interval (fixed point);
+        float tab[TB_GMAX][64];                //        after the emission pass the partial error sums
+        uint32_t hist[TB_GMAX][64];
     };
-    __shared__ Lds lds;
+    uint8_t s3[TB_GMAX][64];                   // 24 KB: kink weight of interval g / S_all in 1/255, rounded up
+    union {                                    // 16 KB
+        struct { float A[2][TB_CH][64], M[2][TB_CH][64]; } st;   // staged set-up, double-buffered
+        float4 L[TB_DW][64];                                     // partial radiances
+        float red[4][TB_DW][64];                                 // partial sums of the range and histogram passes
+    };
+    float st_r[2][TB_CH];                      // r_j of the staged absorbers
+};
+
+// one pass over the survivors for the NT nodes [g0, g0 + NT) of this wave; tab[g] = C - sum_j A_j Erf(x_gj)
+template <int EXP, int ERF, int NT>
+__device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds, uint32_t cnt, const LaneRay &ray,
+                                            float s_first /* node g0 of this lane */, float h, float C, uint32_t g0, uint32_t wave,
+                                            uint32_t lane, uint32_t &n_skip)
+{
+    constexpr float SAT_M = erf_saturation<ERF>() + 1e-3f;
+    const ErfEval<ERF> erf;
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    float common = C;
+    auto stage = [&](uint32_t chunk) {
+        const uint32_t j = chunk * TB_CH + wave, b = chunk & 1u;
+        float A = 0.f, m = 0.f, r = 0.f;
+        if (j < cnt) { // wave-uniform
+            const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
+            const float4 ca = uload(S.gA, idx), cb = uload(S.gB, idx);
+            const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+            const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+            A = cb.z * vexp<EXP>(-(d2 * cb.y));
+            m = mubar * cb.x;
+            r = cb.x;
+        }
+        lds.st.A[b][wave][lane] = A; lds.st.M[b][wave][lane] = m;
+        if (lane == 0) lds.st_r[b][wave] = r;
+    };
+    const uint32_t chunks = (cnt + TB_CH - 1) / TB_CH;
+    stage(0);
+    __syncthreads();
+    for (uint32_t c = 0; c < chunks; ++c) {
+        if (c + 1 < chunks) stage(c + 1);
+        const uint32_t b = c & 1u, nj = min((uint32_t)TB_CH, cnt - c * TB_CH);
+        for (uint32_t jj = 0; jj < nj; ++jj) {
+            const float A = lds.st.A[b][jj][lane], m = lds.st.M[b][jj][lane];
+            const float r = lds.st_r[b][jj];
+            const float hr = h * r;
+            const float x0 = __builtin_fmaf(s_first, r, -m), x1 = __builtin_fmaf((float)(NT - 1), hr, x0);
+            // saturated over the wave's whole node range on all rays: Erf = -1 (absorber behind the nodes) or +1 (in front)
+            if (__all(x1 <= -SAT_M)) { common += A; ++n_skip; continue; }
+            if (__all(x0 >= SAT_M)) { common -= A; ++n_skip; continue; }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(-A, erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+        }
+        __syncthreads(); // chunk c+1 is staged, and everyone is done with buffer b (chunk c+2 goes there)
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (g0 + t < (uint32_t)TB_GMAX) lds.tab[g0 + t][lane] = acc[t] + common;
+}
+
+template <int EXP, int ERF>
+__device__ __forceinline__ void render_table_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R,
+                                                  const RenderTarget &O)
+{
+    constexpr int DW = TB_DW, TC = TB_TC, EC = 4;
+    const ErfEval<ERF> erf;
+    __shared__ TableLds lds;
     __shared__ uint32_t s_wave_cnt[DW];
-    __shared__ uint32_t s_item;
+    __shared__ float s_rmax[DW];
+    __shared__ uint32_t s_item, s_flag;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t npix = (uint64_t)R.width * R.height;
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
@@ -1070,6 +1150,7 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
         __hip_atomic_store(&C.feedback[3], C.frame_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const uint32_t *dense_queue = C.dense_is_sorted ? C.dense_sorted : C.dense;
+    uint32_t n_skip = 0; // (absorber, wave) visits the saturation test settled with one add (statistics)
 
     for (;;) {
         __syncthreads(); // everyone is done with the previous item's LDS
@@ -1114,12 +1195,11 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
             const uint32_t k = base + tid;
             bool keep = false;
             uint32_t idx = 0;
-            float4 a, bq;
             if (k < n_list) {
                 idx = list[k];
-                a = S.gA[idx]; bq = S.gB[idx];
+                float4 bq = S.gB[idx];
                 bq.w = slack_cull_x(bq.w, level_slack(T.cull_ref_n, n_list), T.floor_x);
-                keep = cone_keeps(cone, a, bq);
+                keep = cone_keeps(cone, S.gA[idx], bq);
             }
             const unsigned long long mask = __ballot(keep);
             if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
@@ -1132,112 +1212,225 @@ __global__ __launch_bounds__(1024, 4) void render_table_kernel(SceneTables S, Ti
                 chunk += c;
             }
             const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            if (keep && pos < TC) { lds.idx[pos] = idx; lds.rows.A[pos] = a; lds.rows.B[pos] = bq; }
+            if (keep && pos < TC) lds.idx[pos] = idx;
             cnt += chunk;
             __syncthreads();
         }
 
-        // ---- this ray's sample range and node spacing; is the block eligible? (identical in all 16 waves) ----
+        // ---- every ray's sample range (wave w looks at survivors w, w + 16, ...), the block's node spacing ----
         bool ok = cnt <= (uint32_t)TC && cnt > 0;
         float s_lo = INFINITY, s_hi = -INFINITY, r_max = 0.f;
         if (ok) {
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const float4 a = lds.rows.A[j];
-                const float r = lds.rows.B[j].x;
+            for (uint32_t j = wave; j < cnt; j += DW) {
+                const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
+                const float4 a = uload(S.gA, idx);
+                const float r = uload(S.gB, idx).x;
                 const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
                 s_hi = fmaxf(s_hi, mubar);
                 s_lo = fminf(s_lo, mubar - 2.8285f / r); // mubar - 4 sigma, sigma = 1/(sqrt2 r), rounded outwards
                 r_max = fmaxf(r_max, r);
             }
+            lds.red[0][wave][lane] = s_hi; lds.red[1][wave][lane] = s_lo;
+            if (lane == 0) s_rmax[wave] = r_max;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < DW; ++w) {
+                s_hi = fmaxf(s_hi, lds.red[0][w][lane]); s_lo = fminf(s_lo, lds.red[1][w][lane]);
+                r_max = fmaxf(r_max, s_rmax[w]);
+            }
+            __syncthreads();
         }
-        float h = (s_hi - s_lo) / (float)(G - 5);
-        s_lo -= 2.f * h; // two nodes of margin at either end: every sample has its four neighbours
-        ok = ok && __all(h * r_max <= C.table_hx); // (false for NaN)
+        const float range = wave_max(s_hi - s_lo); // the block's longest sample range
+        float h = C.table_hx / r_max;              // requested spacing: table_hx in units of 1/r of the narrowest Gaussian
+        ok = ok && range >= 0.f && h > 0.f && range < INFINITY; // (false for NaN)
+        bool done = false;
+        for (int attempt = 0; ok && !done; ++attempt) {
+            // Every ray has its own grid of Gtot nodes from its first sample on (two nodes of margin at either end, so that
+            // every sample has its four neighbours), all with the block's spacing.  The table holds TB_GMAX nodes: a deeper
+            // range is worked off in segments of SL intervals (+ the margins); a sample belongs to the segment its interval
+            // lies in.  Segments in empty space cost next to nothing: every absorber is saturated there.
+            const float u = h * r_max;
+            const float gtf = ceilf(range / h) + 6.f;
+            if (!(u <= 0.3f) || !(gtf < 8.f * (float)(TB_GMAX - 8))) { ok = false; break; }
+            const uint32_t Gtot = (uint32_t)gtf;
+            const uint32_t nseg = (Gtot - 6u + (uint32_t)(TB_GMAX - 8) - 1u) / (uint32_t)(TB_GMAX - 8);
+            // intervals per segment; nodes in the table: the segment's intervals, two nodes before them, and up to six behind the
+            // last one (the samples' intervals start at 2 and end at Gtot - 4 <= nseg SL + 2, whose stencil ends at nseg SL + 4)
+            const uint32_t SL = (Gtot - 6u + nseg - 1u) / nseg, G = SL + 8u;
+            const float lo = s_lo - 2.f * h, inv_h = 1.f / h;
+            const uint32_t nt = (G + DW - 1) / DW;
+            const uint32_t NTsel = nt <= 4 ? 4 : nt <= 6 ? 6 : nt <= 8 ? 8 : nt <= 12 ? 12 : nt <= 16 ? 16 : nt <= 20 ? 20 : 24;
+            const uint32_t g0 = wave * NTsel;
+            float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f, b_in = 0.f, b_out = 0.f;
+            float Csum = 0.f, S_all = 0.f;
+
+            for (uint32_t seg = 0; seg < nseg; ++seg) {
+                const float node0 = (float)(seg * SL) - 2.f; // the segment's first node on the ray's grid
+                // ---- kink pass: wave w takes absorbers w, w + 16, ...: the weight of the kink of j (TB_W0 units, fixed
+                //      point, rounded up; integer adds: the order of the atomics does not matter) into the interval of mubar_j
+                //      and its two neighbours; in the first segment also C = sum A_j E_j and S_all = sum |A_j|
+                for (uint32_t g = wave; g < G; g += DW) lds.hist[g][lane] = 0u;
+                __syncthreads();
+                float c_part = 0.f, s_part = 0.f;
+                for (uint32_t j = wave; j < cnt; j += DW) {
+                    const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
+                    const float4 ca = uload(S.gA, idx), cb = uload(S.gB, idx);
+                    const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+                    const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+                    const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
+                    if (seg == 0) {
+                        c_part = __builtin_fmaf(A, erf(-(mubar * cb.x)), c_part);
+                        s_part += fabsf(A);
+                    }
+                    const float pos = (mubar - lo) * inv_h;
+                    const float gb = floorf(pos);
+                    const float th = fminf(fmaxf(pos - gb, 0.f), 1.f);
+                    const float a16 = fminf(fabsf(A), 60.f) * 65536.f;
+                    const float gl = gb - node0; // interval of the kink in this segment's table
+                    if (gl >= 0.f && gl < (float)G) atomicAdd(&lds.hist[(uint32_t)gl][lane], (uint32_t)ceilf(a16 * fminf(1.f, 0.28f + 2.58f * fabsf(th - 0.5f))));
+                    if (gl + 1.f >= 0.f && gl + 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl + 1.f)][lane], (uint32_t)ceilf(a16 * th * th));
+                    if (gl - 1.f >= 0.f && gl - 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl - 1.f)][lane], (uint32_t)ceilf(a16 * (1.f - th) * (1.f - th)));
+                }
+                if (seg == 0) { lds.red[2][wave][lane] = c_part; lds.red[3][wave][lane] = s_part; }
+                __syncthreads();
+                if (seg == 0) {
+#pragma unroll
+                    for (int w = 0; w < DW; ++w) { Csum += lds.red[2][w][lane]; S_all += lds.red[3][w][lane]; }
+                }
+                const float s3_scale = 255.f / (fmaxf(S_all, 1e-30f) * 65536.f);
+                for (uint32_t g = wave; g < G; g += DW)
+                    lds.s3[g][lane] = (uint8_t)fminf(floorf((float)lds.hist[g][lane] * s3_scale) + 1.f, 255.f);
+                __syncthreads(); // the weights are read: their memory becomes the table; the partial sums' memory the staging buffers
+
+                // ---- table: wave w evaluates the nodes [w NT, (w+1) NT) of the segment against all survivors ----
+                const float s_first = __builtin_fmaf(node0 + (float)g0, h, lo);
+                switch (NTsel) {
+                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                }
+                __syncthreads();
+
+                // ---- emission: the emitters are dealt to the waves; X(s_ik) by 4-point Lagrange interpolation for the samples
+                //      of this segment; the error bound is accumulated beside the radiance ----
+                const float seg_lo = (float)(seg * SL), seg_hi = seg + 1 == nseg ? INFINITY : (float)((seg + 1) * SL);
+                for (uint32_t i0 = wave * EC; i0 < cnt; i0 += DW * EC) {
+#pragma unroll
+                    for (int e = 0; e < EC; ++e) {
+                        if (i0 + e >= cnt) break;
+                        const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[i0 + e]);
+                        const float4 a = uload(S.gA, idx);
+                        const float e_mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+                        const float4 ms = uload(S.mu_sig, idx);
+                        const float inv2s2 = uload(S.gB, idx).y;
+                        const float q = uload(S.gD, idx).y;
+                        float inner = 0.f, inner_abs = 0.f, inner_s3 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const float sk = madd_ref((float)(k - 4), ms.w, e_mubar);
+                            const float uu = (sk - lo) * inv_h;
+                            const float gi = fminf(fmaxf(floorf(uu), 2.f), (float)(Gtot - 4)); // interval on the ray's grid
+                            const bool mine = nseg == 1 || (gi >= seg_lo && gi < seg_hi);
+                            const float gfl = mine ? gi - node0 : 2.f; // ... and in the table
+                            const float t = uu - (gfl + node0);
+                            const uint32_t g = (uint32_t)gfl;
+                            const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
+                            const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
+                            const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
+                            const float dd = dot3_ref(px, py, pz, px, py, pz);
+                            const float tm1 = t - 1.f, tm2 = t - 2.f, tp1 = t + 1.f;
+                            const float w0 = t * tm1 * tm2 * (-1.f / 6.f), w1 = tp1 * tm1 * tm2 * 0.5f;
+                            const float w2 = tp1 * t * tm2 * -0.5f, w3 = tp1 * t * tm1 * (1.f / 6.f);
+                            const float X = w0 * lds.tab[g - 1][lane] + w1 * lds.tab[g][lane] + w2 * lds.tab[g + 1][lane] + w3 * lds.tab[g + 2][lane];
+                            const float term = mine ? emission_term<EXP>(q, dd * inv2s2, X) : 0.f;
+                            inner += term;
+                            inner_abs += fabsf(term);
+                            inner_s3 = __builtin_fmaf(fabsf(term), (float)lds.s3[g][lane], inner_s3);
+                        }
+                        const float4 alb = uload(S.gC, idx);
+                        Lr = __builtin_fmaf(alb.x, inner, Lr);
+                        Lg = __builtin_fmaf(alb.y, inner, Lg);
+                        Lb = __builtin_fmaf(alb.z, inner, Lb);
+                        La = __builtin_fmaf(alb.w, inner, La);
+                        const float amax = fmaxf(fmaxf(fabsf(alb.x), fabsf(alb.y)), fmaxf(fabsf(alb.z), fabsf(alb.w)));
+                        b_in = __builtin_fmaf(amax, inner_s3, b_in);
+                        b_out = __builtin_fmaf(amax, inner_abs, b_out);
+                    }
+                }
+                __syncthreads(); // nobody reads the staging buffers or the table any more
+            }
+            lds.L[wave][lane] = make_float4(Lr, Lg, Lb, La);
+            float2 *bparts = reinterpret_cast<float2 *>(&lds.tab[0][0]); // [DW][64]
+            bparts[wave * 64 + lane] = make_float2(b_in, b_out);
+            __syncthreads();
+            if (wave == 0) {
+                float4 sum = lds.L[0][lane];
+                float2 bs = bparts[lane];
+#pragma unroll
+                for (int w = 1; w < DW; ++w) {
+                    const float4 v = lds.L[w][lane];
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    const float2 bv = bparts[w * 64 + lane];
+                    bs.x += bv.x; bs.y += bv.y;
+                }
+                // worst-case change of this ray's radiance (header comment); e^dX - 1 <= 1.01 dX for the dX in question
+                const float e_in = TB_W0 * u * u, e_out = TB_COUT * (u * u) * (u * u);
+                const float bound = 1.01f * S_all * (e_in * (1.f / 255.f) * bs.x + e_out * bs.y);
+                // (false for NaN; S_all beyond the fixed-point range of the weights: no bound)
+                const bool good = !valid || (bound <= C.table_budget && S_all < 60.f);
+                const bool all_good = __all(good);
+                if (all_good && valid) {
+                    if (O.image) O.image[out] = pack_pixel(sum.x, sum.y, sum.z, sum.w, O.pack_flags);
+                    if (O.radiance) O.radiance[out] = sum;
+                }
+                if (lane == 0) s_flag = all_good ? 1u : 0u;
+            }
+            __syncthreads();
+            done = s_flag != 0u;
+            if (!done) {
+                if (attempt >= 1) { ok = false; break; }
+                h *= 0.6f;
+            } else if (O.stats && tid == 0) {
+                atomicAdd(&O.stats[0], (unsigned long long)cnt);
+                atomicAdd(&O.stats[1], (unsigned long long)n_list);
+                atomicAdd(&O.stats[6], 1ull);
+                atomicAdd(&O.stats[7], 1ull);
+                atomicAdd(&O.stats[16], (unsigned long long)Gtot);
+                if (attempt) atomicAdd(&O.stats[17], 1ull);
+            }
+        }
         if (!ok) { // wave-uniform and the same in every wave
-            if (tid == 0) C.overflow2[atomicAdd(C.n_overflow2, 1u)] = (cell << 4) | bi;
+            if (tid == 0) {
+                C.overflow2[atomicAdd(C.n_overflow2, 1u)] = (cell << 4) | bi;
+                if (O.stats) atomicAdd(&O.stats[19], 1ull);
+            }
             continue;
         }
-        if (O.stats && tid == 0) {
-            atomicAdd(&O.stats[0], (unsigned long long)cnt);
-            atomicAdd(&O.stats[1], (unsigned long long)n_list);
-            atomicAdd(&O.stats[6], 1ull);
-            atomicAdd(&O.stats[7], 1ull);
-        }
-        const float inv_h = 1.f / h;
-
-        // ---- table: wave w evaluates nodes w, w + 16, ... against all survivors ----
-        {
-            float s_g[NPW], acc[NPW];
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) { s_g[i] = __builtin_fmaf((float)(wave + DW * i), h, s_lo); acc[i] = 0.f; }
-            float4 a = lds.rows.A[0], b = lds.rows.B[0];
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const float4 ca = a, cb = b;
-                if (j + 1 < cnt) { a = lds.rows.A[j + 1]; b = lds.rows.B[j + 1]; }
-                const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
-                const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
-                const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
-                const float m = mubar * cb.x;
-                const float E = erf(-m);
-#pragma unroll
-                for (int i = 0; i < NPW; ++i) acc[i] = __builtin_fmaf(A, E - erf(__builtin_fmaf(s_g[i], cb.x, -m)), acc[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) lds.tab[wave + DW * i][lane] = acc[i];
-        }
-        __syncthreads();
-
-        // ---- emission: the emitters are dealt to the waves; X(s_ik) by 4-point Lagrange interpolation ----
-        float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
-        for (uint32_t i0 = wave * EC; i0 < cnt; i0 += DW * EC) {
-#pragma unroll
-            for (int e = 0; e < EC; ++e) {
-                if (i0 + e >= cnt) break;
-                const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[i0 + e]);
-                const float4 a = lds.rows.A[i0 + e];
-                const float e_mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
-                const float4 ms = uload(S.mu_sig, idx);
-                const float inv2s2 = lds.rows.B[i0 + e].y;
-                const float q = uload(S.gD, idx).y;
-                float inner = 0.f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const float sk = madd_ref((float)(k - 4), ms.w, e_mubar);
-                    const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
-                    const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
-                    const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
-                    const float dd = dot3_ref(px, py, pz, px, py, pz);
-                    const float u = (sk - s_lo) * inv_h;
-                    const float gf = fminf(fmaxf(floorf(u), 1.f), (float)(G - 3));
-                    const float t = u - gf;
-                    const uint32_t g = (uint32_t)gf;
-                    const float tm1 = t - 1.f, tm2 = t - 2.f, tp1 = t + 1.f;
-                    const float w0 = t * tm1 * tm2 * (-1.f / 6.f), w1 = tp1 * tm1 * tm2 * 0.5f;
-                    const float w2 = tp1 * t * tm2 * -0.5f, w3 = tp1 * t * tm1 * (1.f / 6.f);
-                    const float X = w0 * lds.tab[g - 1][lane] + w1 * lds.tab[g][lane] + w2 * lds.tab[g + 1][lane] + w3 * lds.tab[g + 2][lane];
-                    inner += emission_term<EXP>(q, dd * inv2s2, X);
-                }
-                const float4 alb = uload(S.gC, idx);
-                Lr = __builtin_fmaf(alb.x, inner, Lr);
-                Lg = __builtin_fmaf(alb.y, inner, Lg);
-                Lb = __builtin_fmaf(alb.z, inner, Lb);
-                La = __builtin_fmaf(alb.w, inner, La);
-            }
-        }
-        __syncthreads(); // nobody reads the parameter rows any more: their LDS becomes the partial radiances
-        lds.L[wave][lane] = make_float4(Lr, Lg, Lb, La);
-        __syncthreads();
-        if (wave == 0 && valid) {
-            float4 sum = lds.L[0][lane];
-#pragma unroll
-            for (int w = 1; w < DW; ++w) {
-                const float4 v = lds.L[w][lane];
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-            }
-            if (O.image) O.image[out] = pack_pixel(sum.x, sum.y, sum.z, sum.w, O.pack_flags);
-            if (O.radiance) O.radiance[out] = sum;
-        }
     }
+    if (O.stats && lane == 0) atomicAdd(&O.stats[18], (unsigned long long)n_skip);
+}
+
+template <int EXP, int ERF>
+__global__ __launch_bounds__(1024) void render_table_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+{
+    render_table_body<EXP, ERF>(S, T, C, R, O);
+}
+// several frames per launch: blockIdx.y is the frame; C2 is the frame's second queue (what the table kernel declines)
+template <int EXP, int ERF>
+__global__ __launch_bounds__(1024) void render_table_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    render_table_body<EXP, ERF>(a.S, a.T, a.C, a.R, a.O);
+}
+template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
+__global__ __launch_bounds__(DW * 64, 4) void render_dense_batch2_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C2, a.R, a.O);
 }
 
 // Queue order of the dense kernel: cells by descending candidate count (a block costs ~ count^2), so that the
@@ -1351,6 +1544,15 @@ void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint
     VRT_DISPATCH_EXP_ERF(launch_render_dense_batch_t, d_frames, nframes, grid, dw, st);
 }
 
+// The table kernel's error bound is that of the Abramowitz-Stegun erf (its kink) or of a smoother one (libm); the Exp must
+// be an accurate one (Exp(a)Exp(b) = Exp(a + b)): four pairs are instantiated, the host keeps every other pair exact.
+#define VRT_DISPATCH_TABLE(FN, ...)                                                                \
+    switch (exp_kind * 8 + erf_kind) {                                                             \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM>(__VA_ARGS__); break;      \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS>(__VA_ARGS__); break;          \
+    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM>(__VA_ARGS__); break;        \
+    default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
+    }
 template <int EXP, int ERF>
 static void launch_render_table_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                                   const RenderTarget &o, uint32_t grid, hipStream_t st)
@@ -1361,7 +1563,25 @@ static void launch_render_table_t(const SceneTables &s, const TileLists &t, cons
 void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
-    VRT_DISPATCH_EXP_ERF(launch_render_table_t, s, t, c, r, o, grid, st);
+    VRT_DISPATCH_TABLE(launch_render_table_t, s, t, c, r, o, grid, st);
+}
+template <int EXP, int ERF>
+static void launch_render_table_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, hipStream_t st)
+{
+    if (!nframes) return;
+    if (grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF>), dim3(grid, nframes), dim3(1024), 0, st, d_frames);
+    if (!grid2) return;
+    const dim3 g(grid2, nframes);
+    if (dw == 17) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 16, false>), g, dim3(1024), 0, st, d_frames);
+    else if (dw == 16) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 16>), g, dim3(1024), 0, st, d_frames);
+    else if (dw == 8) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 8>), g, dim3(512), 0, st, d_frames);
+    else hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 4>), g, dim3(256), 0, st, d_frames);
+}
+// table kernel over the frames' dense queues, then the exact kernel over what it declined (FrameArgs::C2)
+void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, int exp_kind, int erf_kind,
+                               hipStream_t st)
+{
+    VRT_DISPATCH_TABLE(launch_render_table_batch_t, d_frames, nframes, grid, grid2, dw, st);
 }
 
 // ---------------------------------------------------------------------------------------------
