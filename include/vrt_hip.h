@@ -308,6 +308,8 @@ typedef struct {
     uint64_t table_retries;   /* blocks that met the error budget only at the reduced spacing                */
     uint64_t table_skips;     /* (absorber, wave) visits settled by saturation (one add instead of NT terms) */
     uint64_t table_declined;  /* blocks handed to the exact kernel                                           */
+    uint64_t table_coarser;   /* blocks done at a coarser spacing than requested (the bound left room)       */
+    uint64_t table_empty;     /* of table_blocks, blocks no Gaussian reaches (the rim of a dense cell)       */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

@@ -21,6 +21,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 EXP_LIBM, EXP_VCL, EXP_FAST, EXP_SPLINE = 0, 1, 2, 3
 ERF_LIBM, ERF_AS, ERF_SPLINE, ERF_SPLINE_MIRROR, ERF_TAYLOR = 0, 1, 2, 3, 4
+TABLE_STEP_DEFAULT = 0.05   # vrt_hip_set_table_step: the library's default (0 = exact kernels only)
 PACK_TRUNC, PACK_ROUND, ALPHA_OPAQUE, ALPHA_COMPUTED = 0, 1, 0, 2
 
 _lib = None
@@ -37,7 +38,7 @@ class Stats(C.Structure):
                 ("dense_busy_frac", C.c_double), ("table_blocks", C.c_uint64),
                 ("lane_pairs", C.c_uint64), ("dense_visits_full", C.c_uint64), ("dense_visits_zero", C.c_uint64),
                 ("dense_visits_common", C.c_uint64), ("table_nodes", C.c_uint64), ("table_retries", C.c_uint64),
-                ("table_skips", C.c_uint64), ("table_declined", C.c_uint64)]
+                ("table_skips", C.c_uint64), ("table_declined", C.c_uint64), ("table_coarser", C.c_uint64), ("table_empty", C.c_uint64)]
 
 
 def build(verbose=False):
@@ -158,6 +159,7 @@ class Renderer:
         self._h = _handle
         self.n = 0
         self.w = self.h = 0
+        self.table_step = float(os.environ.get("VRT_HIP_TABLE_STEP", TABLE_STEP_DEFAULT))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -416,6 +418,7 @@ class Renderer:
     def set_table_step(self, step):
         """Table mode for dense blocks (default 0.05; 0 = exact kernels only): see vrt_hip_set_table_step in include/vrt_hip.h."""
         self._chk(self._L.vrt_hip_set_table_step(self._h, float(step)), "set_table_step")
+        self.table_step = float(step)
 
     def set_table_budget(self, budget):
         """Largest worst-case change of a ray's radiance the table kernel may cause (default 2.5e-5)."""

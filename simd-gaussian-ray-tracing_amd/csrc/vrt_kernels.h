@@ -93,6 +93,8 @@ struct CellGrid {
     // radiance the table may cause (worst-case bound, checked per ray), and the queue of the blocks it declines, which
     // the exact dense kernel works off afterwards
     float table_hx, table_budget;
+    float table_adapt;               // the table kernel may choose a spacing up to this many times the requested one where its estimate
+                                     // of the error bound leaves room (1 = always as requested)
     uint32_t *overflow2, *n_overflow2;
 };
 constexpr uint32_t RQ_N = 8, RQ_STRIDE = 64;
@@ -133,7 +135,8 @@ struct RenderTarget {
                                // [6]=dense blocks [7]=table blocks [8..11]=dense workgroup timeline [12]=sum over rays of (lane list length)^2
                                // [13..15]=dense kernel: (emitter chunk, absorber) visits evaluated in full / exactly zero / exactly -2A
                                // [16]=table kernel: sum of node counts over its blocks [17]=blocks it did at the reduced spacing
-                               // [18]=(absorber, wave) visits it settled by saturation [19]=blocks it declined   (24 words in all)
+                               // [18]=(absorber, wave) visits it settled by saturation [19]=blocks it declined [20]=blocks it did at a coarser spacing
+                               // than requested [21]=blocks of its queue that no Gaussian reaches   (24 words in all)
     unsigned long long *timeline; // nullable diagnostics: 4 wall_clock64 stamps + the hardware id per one-wave work item (5 words)
 };
 

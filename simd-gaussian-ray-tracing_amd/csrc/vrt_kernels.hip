@@ -1073,18 +1073,20 @@ struct TableLds {
         uint32_t hist[TB_GMAX][64];
     };
     uint8_t s3[TB_GMAX][64];                   // 24 KB: kink weight of interval g / S_all in 1/255, rounded up
-    union {                                    // 16 KB
-        struct { float A[2][TB_CH][64], M[2][TB_CH][64]; } st;   // staged set-up, double-buffered
+    union {                                    // 24 KB
+        struct { float A[2][TB_CH][64], M[2][TB_CH][64], E[2][TB_CH][64]; } st;   // staged set-up, double-buffered
         float4 L[TB_DW][64];                                     // partial radiances
         float red[4][TB_DW][64];                                 // partial sums of the range and histogram passes
     };
     float st_r[2][TB_CH];                      // r_j of the staged absorbers
 };
 
-// one pass over the survivors for the NT nodes [g0, g0 + NT) of this wave; tab[g] = C - sum_j A_j Erf(x_gj)
+// one pass over the survivors for the NT nodes [g0, g0 + NT) of this wave; tab[g] = sum_j A_j (E_j - Erf(x_gj)), summed per term
+// like the exact kernels (C - sum A_j Erf would round at the magnitude of sum |A_j|: 5e-5 of radiance for 1500 wide Gaussians,
+// tests/fuzz_parity.py seed 3 case 6)
 template <int EXP, int ERF, int NT>
 __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds, uint32_t cnt, const LaneRay &ray,
-                                            float s_first /* node g0 of this lane */, float h, float C, uint32_t g0, uint32_t wave,
+                                            float s_first /* node g0 of this lane */, float h, uint32_t g0, uint32_t wave,
                                             uint32_t lane, uint32_t &n_skip)
 {
     constexpr float SAT_M = erf_saturation<ERF>() + 1e-3f;
@@ -1092,10 +1094,10 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
     float acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
-    float common = C;
+    float common = 0.f;
     auto stage = [&](uint32_t chunk) {
         const uint32_t j = chunk * TB_CH + wave, b = chunk & 1u;
-        float A = 0.f, m = 0.f, r = 0.f;
+        float A = 0.f, m = 0.f, r = 0.f, E = 0.f;
         if (j < cnt) { // wave-uniform
             const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
             const float4 ca = uload(S.gA, idx), cb = uload(S.gB, idx);
@@ -1103,9 +1105,10 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
             const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
             A = cb.z * vexp<EXP>(-(d2 * cb.y));
             m = mubar * cb.x;
+            E = erf(-m);
             r = cb.x;
         }
-        lds.st.A[b][wave][lane] = A; lds.st.M[b][wave][lane] = m;
+        lds.st.A[b][wave][lane] = A; lds.st.M[b][wave][lane] = m; lds.st.E[b][wave][lane] = E;
         if (lane == 0) lds.st_r[b][wave] = r;
     };
     const uint32_t chunks = (cnt + TB_CH - 1) / TB_CH;
@@ -1115,15 +1118,15 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
         if (c + 1 < chunks) stage(c + 1);
         const uint32_t b = c & 1u, nj = min((uint32_t)TB_CH, cnt - c * TB_CH);
         for (uint32_t jj = 0; jj < nj; ++jj) {
-            const float A = lds.st.A[b][jj][lane], m = lds.st.M[b][jj][lane];
+            const float A = lds.st.A[b][jj][lane], m = lds.st.M[b][jj][lane], E = lds.st.E[b][jj][lane];
             const float r = lds.st_r[b][jj];
             const float hr = h * r;
             const float x0 = __builtin_fmaf(s_first, r, -m), x1 = __builtin_fmaf((float)(NT - 1), hr, x0);
             // saturated over the wave's whole node range on all rays: Erf = -1 (absorber behind the nodes) or +1 (in front)
-            if (__all(x1 <= -SAT_M)) { common += A; ++n_skip; continue; }
-            if (__all(x0 >= SAT_M)) { common -= A; ++n_skip; continue; }
+            if (__all(x1 <= -SAT_M)) { common = __builtin_fmaf(A, E + 1.f, common); ++n_skip; continue; }
+            if (__all(x0 >= SAT_M)) { common = __builtin_fmaf(A, E - 1.f, common); ++n_skip; continue; }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(-A, erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
         }
         __syncthreads(); // chunk c+1 is staged, and everyone is done with buffer b (chunk c+2 goes there)
     }
@@ -1137,7 +1140,6 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                                                   const RenderTarget &O)
 {
     constexpr int DW = TB_DW, TC = TB_TC, EC = 4;
-    const ErfEval<ERF> erf;
     __shared__ TableLds lds;
     __shared__ uint32_t s_wave_cnt[DW];
     __shared__ float s_rmax[DW];
@@ -1217,8 +1219,16 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             __syncthreads();
         }
 
+        if (cnt == 0) { // nothing reaches this block (the rim of a dense cell): background
+            if (wave == 0 && valid) {
+                if (O.image) O.image[out] = pack_pixel(0.f, 0.f, 0.f, 0.f, O.pack_flags);
+                if (O.radiance) O.radiance[out] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (O.stats && tid == 0) { atomicAdd(&O.stats[1], (unsigned long long)n_list); atomicAdd(&O.stats[6], 1ull); atomicAdd(&O.stats[7], 1ull); atomicAdd(&O.stats[21], 1ull); }
+            continue;
+        }
         // ---- every ray's sample range (wave w looks at survivors w, w + 16, ...), the block's node spacing ----
-        bool ok = cnt <= (uint32_t)TC && cnt > 0;
+        bool ok = cnt <= (uint32_t)TC;
         float s_lo = INFINITY, s_hi = -INFINITY, r_max = 0.f;
         if (ok) {
             for (uint32_t j = wave; j < cnt; j += DW) {
@@ -1241,47 +1251,53 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             __syncthreads();
         }
         const float range = wave_max(s_hi - s_lo); // the block's longest sample range
-        float h = C.table_hx / r_max;              // requested spacing: table_hx in units of 1/r of the narrowest Gaussian
-        ok = ok && range >= 0.f && h > 0.f && range < INFINITY; // (false for NaN)
+        const float h_req = C.table_hx / r_max;    // requested spacing: table_hx in units of 1/r of the narrowest Gaussian
+        ok = ok && range >= 0.f && h_req > 0.f && range < INFINITY; // (false for NaN)
         bool done = false;
+        float h_target = h_req;
         for (int attempt = 0; ok && !done; ++attempt) {
             // Every ray has its own grid of Gtot nodes from its first sample on (two nodes of margin at either end, so that
             // every sample has its four neighbours), all with the block's spacing.  The table holds TB_GMAX nodes: a deeper
             // range is worked off in segments of SL intervals (+ the margins); a sample belongs to the segment its interval
-            // lies in.  Segments in empty space cost next to nothing: every absorber is saturated there.
-            const float u = h * r_max;
-            const float gtf = ceilf(range / h) + 6.f;
-            if (!(u <= 0.3f) || !(gtf < 8.f * (float)(TB_GMAX - 8))) { ok = false; break; }
-            const uint32_t Gtot = (uint32_t)gtf;
-            const uint32_t nseg = (Gtot - 6u + (uint32_t)(TB_GMAX - 8) - 1u) / (uint32_t)(TB_GMAX - 8);
-            // intervals per segment; nodes in the table: the segment's intervals, two nodes before them, and up to six behind the
-            // last one (the samples' intervals start at 2 and end at Gtot - 4 <= nseg SL + 2, whose stencil ends at nseg SL + 4)
-            const uint32_t SL = (Gtot - 6u + nseg - 1u) / nseg, G = SL + 8u;
-            const float lo = s_lo - 2.f * h, inv_h = 1.f / h;
-            const uint32_t nt = (G + DW - 1) / DW;
-            const uint32_t NTsel = nt <= 4 ? 4 : nt <= 6 ? 6 : nt <= 8 ? 8 : nt <= 12 ? 12 : nt <= 16 ? 16 : nt <= 20 ? 20 : 24;
-            const uint32_t g0 = wave * NTsel;
-            float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f, b_in = 0.f, b_out = 0.f;
-            float Csum = 0.f, S_all = 0.f;
+            // lies in.  Segments in empty space cost next to nothing: every absorber is saturated there.  The waves evaluate
+            // NT nodes each, NT from a short menu: the spacing is then REDUCED until the segments fill 16 NT nodes exactly.
+            float h = 0.f, u = 0.f, lo = 0.f, inv_h = 0.f;
+            uint32_t nseg = 0, SL = 0, G = 0, NTsel = 0, Gtot = 0;
+            auto plan = [&](float ht) -> bool {
+                const float need = ceilf(range / ht); // intervals the samples span
+                if (!(need < 8.f * (float)(TB_GMAX - 8))) return false;
+                nseg = max(1u, ((uint32_t)need + (uint32_t)(TB_GMAX - 8) - 1u) / (uint32_t)(TB_GMAX - 8));
+                const uint32_t sl_need = max(1u, ((uint32_t)need + nseg - 1u) / nseg);
+                const uint32_t nt = (sl_need + 8u + DW - 1) / DW;
+                NTsel = nt <= 4 ? 4 : nt <= 6 ? 6 : nt <= 8 ? 8 : nt <= 12 ? 12 : nt <= 16 ? 16 : nt <= 20 ? 20 : 24;
+                // intervals per segment; nodes in the table: the segment's intervals, two nodes before them, and up to six behind
+                // the last one (the samples' intervals start at 2 and end at Gtot - 4 <= nseg SL + 2, whose stencil ends at nseg SL + 4)
+                G = NTsel * DW; SL = G - 8u;
+                h = fminf(ht, range / (float)(nseg * SL) * 1.00001f);
+                if (!(h > 0.f)) h = ht; // range == 0: one sample point per ray
+                u = h * r_max;
+                Gtot = nseg * SL + 6u;
+                lo = s_lo - 2.f * h; inv_h = 1.f / h;
+                return u <= 0.3f;
+            };
+            if (!plan(h_target)) { ok = false; break; }
 
-            for (uint32_t seg = 0; seg < nseg; ++seg) {
+            float S_all = 0.f;
+            // ---- kink pass for one segment: wave w takes absorbers w, w + 16, ...: the weight of the kink of j (TB_W0 units,
+            //      fixed point, rounded up; integer adds: the order of the atomics does not matter) into the interval of mubar_j
+            //      and its two neighbours; with `sums` also S_all = sum |A_j| ----
+            auto kink_pass = [&](uint32_t seg, bool sums) {
                 const float node0 = (float)(seg * SL) - 2.f; // the segment's first node on the ray's grid
-                // ---- kink pass: wave w takes absorbers w, w + 16, ...: the weight of the kink of j (TB_W0 units, fixed
-                //      point, rounded up; integer adds: the order of the atomics does not matter) into the interval of mubar_j
-                //      and its two neighbours; in the first segment also C = sum A_j E_j and S_all = sum |A_j|
                 for (uint32_t g = wave; g < G; g += DW) lds.hist[g][lane] = 0u;
                 __syncthreads();
-                float c_part = 0.f, s_part = 0.f;
+                float s_part = 0.f;
                 for (uint32_t j = wave; j < cnt; j += DW) {
                     const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
                     const float4 ca = uload(S.gA, idx), cb = uload(S.gB, idx);
                     const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
                     const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
                     const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
-                    if (seg == 0) {
-                        c_part = __builtin_fmaf(A, erf(-(mubar * cb.x)), c_part);
-                        s_part += fabsf(A);
-                    }
+                    if (sums) s_part += fabsf(A);
                     const float pos = (mubar - lo) * inv_h;
                     const float gb = floorf(pos);
                     const float th = fminf(fmaxf(pos - gb, 0.f), 1.f);
@@ -1291,12 +1307,78 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                     if (gl + 1.f >= 0.f && gl + 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl + 1.f)][lane], (uint32_t)ceilf(a16 * th * th));
                     if (gl - 1.f >= 0.f && gl - 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl - 1.f)][lane], (uint32_t)ceilf(a16 * (1.f - th) * (1.f - th)));
                 }
-                if (seg == 0) { lds.red[2][wave][lane] = c_part; lds.red[3][wave][lane] = s_part; }
+                if (sums) lds.red[3][wave][lane] = s_part;
                 __syncthreads();
-                if (seg == 0) {
+                if (sums) {
+                    S_all = 0.f;
 #pragma unroll
-                    for (int w = 0; w < DW; ++w) { Csum += lds.red[2][w][lane]; S_all += lds.red[3][w][lane]; }
+                    for (int w = 0; w < DW; ++w) S_all += lds.red[3][w][lane];
                 }
+            };
+
+            // ---- first attempt: how much coarser than requested may the nodes be?  An ESTIMATE of the bound the emission pass
+            //      will find, from the kink weights at the requested spacing: emission of interval g ~ 1.4 D_g T_g with
+            //      D_g = K_g / 1.35 the absorber mass of the interval and T_g = exp(-2 sum of the mass before it); the estimate
+            //      scales with the spacing like kappa^3 (kink part) and kappa^4 (smooth part).  It only picks the spacing: the
+            //      bound itself is checked below, and a block that fails it is redone at 0.6 of the spacing. ----
+            bool have_kinks = false; // the kink weights of segment 0 at the final spacing are in LDS
+            bool have_sums = false;  // S_all is known (it does not depend on the spacing)
+            if (attempt == 0 && C.table_adapt > 1.f) {
+                float P = 0.f, pin = 0.f, pout = 0.f;
+                for (uint32_t seg = 0; seg < nseg; ++seg) {
+                    kink_pass(seg, seg == 0);
+                    const uint32_t ga = seg ? 2u : 0u, gz = min(G, SL + 2u); // the segment's own intervals
+                    const uint32_t wa = min(gz, ga + wave * NTsel), wz = min(gz, wa + NTsel);
+                    float mass = 0.f;
+                    for (uint32_t g = wa; g < wz; ++g) mass += (float)lds.hist[g][lane];
+                    lds.red[0][wave][lane] = mass * (1.f / (1.35f * 65536.f));
+                    __syncthreads();
+                    float before = P, total = 0.f;
+#pragma unroll
+                    for (int w = 0; w < DW; ++w) {
+                        const float mw = lds.red[0][w][lane];
+                        before += (uint32_t)w < wave ? mw : 0.f;
+                        total += mw;
+                    }
+                    for (uint32_t g = wa; g < wz; ++g) {
+                        const float Kg = (float)lds.hist[g][lane] * (1.f / 65536.f), D = Kg * (1.f / 1.35f);
+                        const float e = 1.4f * D * __expf(-2.f * before);
+                        pin = __builtin_fmaf(e, Kg, pin); pout += e;
+                        before += D;
+                    }
+                    P += total;
+                    __syncthreads(); // red[0] is rewritten by the next segment
+                }
+                have_sums = true;
+                lds.red[0][wave][lane] = pin; lds.red[1][wave][lane] = pout;
+                __syncthreads();
+                float pin_t = 0.f, pout_t = 0.f;
+#pragma unroll
+                for (int w = 0; w < DW; ++w) { pin_t += lds.red[0][w][lane]; pout_t += lds.red[1][w][lane]; }
+                const float est_in = 1.01f * TB_W0 * u * u * pin_t, est_out = 1.01f * TB_COUT * (u * u) * (u * u) * S_all * pout_t;
+                float kappa = 1.f;
+                const float room = 0.6f * C.table_budget;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const float k = c == 0 ? 3.f : c == 1 ? 2.5f : c == 2 ? 2.f : c == 3 ? 1.6f : 1.3f;
+                    if (kappa == 1.f && k <= C.table_adapt && k * u <= 0.3f && k * k * k * (est_in + k * est_out) <= room) kappa = k;
+                }
+                kappa = wave_min(valid ? kappa : 3.f); // the same in every wave: they hold the same rays
+                __syncthreads();
+                const float h_before = h;
+                const uint32_t nodes_before = nseg * NTsel, nseg_before = nseg;
+                if (kappa > 1.f && (!plan(h * kappa) || nseg * NTsel >= nodes_before)) { // the menu has no smaller table: as requested
+                    if (!plan(h_target)) { ok = false; break; }
+                }
+                have_kinks = h == h_before && nseg_before == 1u; // segment 0's weights at this spacing are still in LDS
+                if (O.stats && tid == 0 && h != h_before) atomicAdd(&O.stats[20], 1ull);
+            }
+            const uint32_t g0 = wave * NTsel;
+            float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f, b_in = 0.f, b_out = 0.f;
+
+            for (uint32_t seg = 0; seg < nseg; ++seg) {
+                const float node0 = (float)(seg * SL) - 2.f; // the segment's first node on the ray's grid
+                if (!(seg == 0 && have_kinks)) kink_pass(seg, seg == 0 && !have_sums);
                 const float s3_scale = 255.f / (fmaxf(S_all, 1e-30f) * 65536.f);
                 for (uint32_t g = wave; g < G; g += DW)
                     lds.s3[g][lane] = (uint8_t)fminf(floorf((float)lds.hist[g][lane] * s3_scale) + 1.f, 255.f);
@@ -1305,13 +1387,13 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 // ---- table: wave w evaluates the nodes [w NT, (w+1) NT) of the segment against all survivors ----
                 const float s_first = __builtin_fmaf(node0 + (float)g0, h, lo);
                 switch (NTsel) {
-                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
-                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
-                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
-                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
-                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
-                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
-                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, Csum, g0, wave, lane, n_skip); break;
+                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
                 }
                 __syncthreads();
 
@@ -1393,7 +1475,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             done = s_flag != 0u;
             if (!done) {
                 if (attempt >= 1) { ok = false; break; }
-                h *= 0.6f;
+                h_target = 0.6f * h;
             } else if (O.stats && tid == 0) {
                 atomicAdd(&O.stats[0], (unsigned long long)cnt);
                 atomicAdd(&O.stats[1], (unsigned long long)n_list);

@@ -39,10 +39,19 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
-def renderer(pkg):
+def _shared_renderer(pkg):
     r = pkg.Renderer(0)   # raises if the HIP library or the GPU is missing -- no fallback
     yield r
     r.close()
+
+
+@pytest.fixture
+def renderer(pkg, _shared_renderer):
+    """One context for the whole session; every test gets it with the library's default table settings (tests that switch
+    to the exact kernels or another step must not leak that into the next test)."""
+    _shared_renderer.set_table_step(pkg.TABLE_STEP_DEFAULT)
+    _shared_renderer.set_table_budget(2.5e-5)
+    return _shared_renderer
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -31,7 +31,9 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     cam, _ = O.cli_camera(w, h, initial_rot=float(rng.choice([0.0, 30.0, 180.0])))
     plane = O.camera_plane(cam); view = O.camera_view(cam); origin = np.array(cam.position[:], np.float32)
     eps = float(rng.choice([1e-9, 0.0]))
-    r.set_gaussians(g); r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps); r.set_plane(w, h, *plane); r.set_table_step(0.0)
+    r.set_gaussians(g); r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps); r.set_plane(w, h, *plane)
+    tstep = pkg.TABLE_STEP_DEFAULT if case % 2 else 0.0   # table mode (the default) / the exact kernels only
+    r.set_table_step(tstep)
     if tiles_n: r.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, view); tiles = O.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, g, view)
     else: r.clear_tiles(); tiles = None
     img, rad = r.render(origin)
@@ -48,5 +50,5 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     pxd = int(np.abs(((img.reshape(-1)[pix][:, None] >> np.array([16, 8, 0, 24])) & 255).astype(int) - ((oimg[pix][:, None] >> np.array([16, 8, 0, 24])) & 255).astype(int)).max())
     worst = max(worst, err)
     flag = "  <-- FAIL" if (err > 1e-4 or not both_nan.all() or pxd > 1) else ""
-    print(f"case {case}: {kind:10s} n={n} {w}x{h} tiles={tiles_n} eps={eps:g} peak={np.nanmax(orad):.3g} nonfinite {int((~fin).sum())}: rel err {err:.2e} u8 diff {pxd}{flag}", flush=True)
+    print(f"case {case}: {kind:10s} n={n} {w}x{h} tiles={tiles_n} eps={eps:g} table={tstep:g} peak={np.nanmax(orad):.3g} nonfinite {int((~fin).sum())}: rel err {err:.2e} u8 diff {pxd}{flag}", flush=True)
 print("worst", worst)

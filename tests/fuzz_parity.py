@@ -4,7 +4,7 @@
 
 Random scenes (1 .. 1500 Gaussians, sigma .01 .. .4), image sizes, tile counts (0 = untiled, ragged geometries),
 cameras on the CLI's orbit, plane-array and in-kernel rays, cull_eps 1e-9 and 0: the HIP path against the oracle on the
-bright pixels plus a few random ones (tolerance 1e-4), and the opt-in table mode against the exact kernels.
+bright pixels plus a few random ones (tolerance 1e-4), and table mode (the default) against the exact kernels (its budget).
 Round 1: about 1700 cases over a dozen seeds: worst deviation from the oracle 1.2e-6, worst table-mode deviation 6.9e-6;
 in-kernel rays from the view matrix (vrt_hip_set_camera_view) give the plane-array image bit for bit.  The run found
 two things since fixed: tile cones are invalid when the reference's row stride differs from the image width, and the
@@ -40,7 +40,10 @@ for case in range(ncase):
         r.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, view); tiles = O.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, g, view)
     else:
         r.clear_tiles(); tiles = None
-    r.set_table_step(0.0)
+    # dense blocks through the table kernel (the library's default) or the exact kernels only: everything below -- the oracle
+    # comparison and every bit-identity check between entry points -- runs under the case's setting
+    tstep = float(rng.choice([0.0, pkg.TABLE_STEP_DEFAULT, pkg.TABLE_STEP_DEFAULT]))
+    r.set_table_step(tstep)
     img, rad = r.render(origin)
     lum = rad.reshape(-1, 4)[:, :3].sum(1)
     bright = np.nonzero(lum > 0.02)[0]
@@ -50,10 +53,10 @@ for case in range(ncase):
         pix = pix[pix < min(w * h, tw_ * tiles_n * th_ * tiles_n)]
     _, orad = O.render(w, h, plane, origin, g, tiles, pixels=pix, want_image=False)
     err = np.abs(rad.reshape(-1, 4)[pix] - orad).max() if len(pix) else 0.0
-    r.set_table_step(0.12)
+    r.set_table_step(0.0 if tstep else pkg.TABLE_STEP_DEFAULT)   # the other setting: table mode against the exact kernels
     _, rad_t = r.render(origin)
     errt = np.abs(rad_t - rad).max()
-    r.set_table_step(0.0)
+    r.set_table_step(tstep)
     errb = 0.0
     if use_basis:   # in-kernel rays from the view matrix: the same rays bit for bit, so the same image
         r.set_camera_view(w, h, view)
@@ -113,7 +116,7 @@ for case in range(ncase):
         # the same frame three times in ONE launch of each kernel (frame batch on three contexts), then the sparse shards of
         # one rank as a batch, assembled with the batched retained assembly into buffers that hold the previous case
         for x in batch_ctxs:
-            x.set_gaussians(g); x.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps); x.set_table_step(0.0); x.set_shard(0, 1)
+            x.set_gaussians(g); x.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps); x.set_table_step(tstep); x.set_shard(0, 1)
             x.set_camera_view(w, h, view)
         try:
             pk = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
@@ -167,10 +170,10 @@ for case in range(ncase):
             errb = max(errb, 1.0)
         r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps)
     worst = max(worst, err)
-    flag = "  <-- FAIL" if (err > 1e-4 or errt > 1e-4 or errb != 0.0) else ""
+    flag = "  <-- FAIL" if (err > 1e-4 or errt > 3e-5 or errb != 0.0) else ""   # table vs exact: its budget of 2.5e-5 + fp32 noise
     if flag and os.environ.get("VRT_FUZZ_DUMP"):   # keep the case for a float64 post-mortem
         np.savez(os.path.join(os.environ["VRT_FUZZ_DUMP"], f"fuzz_case_{case}.npz"), g=g, xs=plane[0], ys=plane[1], zs=plane[2],
                  origin=origin, pix=pix, gpu=rad.reshape(-1, 4)[pix], oracle=orad, w=w, h=h, tiles_n=tiles_n, view=view,
                  offsets=tiles["offsets"] if tiles else np.zeros(0), indices=tiles["indices"] if tiles else np.zeros(0))
-    print(f"case {case}: n={n} {w}x{h} tiles={tiles_n} sigma=[{sig_lo},{sig_hi}] eps={eps:g} peak={rad.max():.3f}: vs oracle {err:.2e}  table vs exact {errt:.2e}  view-mode rays vs plane arrays {errb:.2e}{extra}{flag}", flush=True)
+    print(f"case {case}: n={n} {w}x{h} tiles={tiles_n} sigma=[{sig_lo},{sig_hi}] eps={eps:g} peak={rad.max():.3f}: vs oracle {err:.2e}  table {tstep:g} | table vs exact {errt:.2e}  view-mode rays vs plane arrays {errb:.2e}{extra}{flag}", flush=True)
 print("worst vs oracle", worst)

@@ -40,7 +40,7 @@ def new_camera(st):
     st["plane"] = O.camera_plane(cam); st["view"] = O.camera_view(cam); st["origin"] = np.array(cam.position[:], np.float32)
 
 
-state = {"g": new_scene(), "rays": "view", "tiles": ("device", 4), "opt": (pkg.EXP_VCL, pkg.ERF_AS, 1e-9), "table": 0.0, "shard": (0, 1)}
+state = {"g": new_scene(), "rays": "view", "tiles": ("device", 4), "opt": (pkg.EXP_VCL, pkg.ERF_AS, 1e-9), "table": 0.05, "shard": (0, 1)}
 new_camera(state)
 
 
@@ -131,7 +131,7 @@ for step in range(nsteps):
         e, f = VARIANTS[int(rng.integers(len(VARIANTS)))]
         state["opt"] = (e, f, float(rng.choice([1e-9, 1e-9, 0.0, 1e-6])))
     elif op == "table":
-        state["table"] = float(rng.choice([0.0, 0.12]))
+        state["table"] = float(rng.choice([0.0, 0.05, 0.12]))
     elif op == "shard":
         world = int(rng.choice([1, 1, 2, 3, 8])); state["shard"] = (int(rng.integers(world)), world)
     if op != "none":

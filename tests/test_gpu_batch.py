@@ -13,21 +13,25 @@ pytestmark = pytest.mark.gpu
 OBJ = os.path.join(GOLDEN, "test-objects")
 
 
-def make_contexts(pkg, n, g, w, h, cam0, shard=(0, 1)):
+def make_contexts(pkg, n, g, w, h, cam0, shard=(0, 1), table=None):
     ctxs = []
     for _ in range(n):
         r = pkg.Renderer(0)
         r.set_gaussians(g)
         r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+        if table is not None:
+            r.set_table_step(table)
         r.set_camera_view(w, h, cam0.view)
         r.set_shard(*shard)
         ctxs.append(r)
     return ctxs
 
 
-@pytest.mark.parametrize("name,w,h,tiles_n,n", [("g64", 768, 768, 16, 5), ("g16", 512, 384, 8, 16), ("monkey", 256, 256, 8, 3),
-                                                 ("cube", 200, 136, 5, 4)])
-def test_batch_equals_single_frames(pkg, renderer, name, w, h, tiles_n, n):
+@pytest.mark.parametrize("name,w,h,tiles_n,n,table", [("g64", 768, 768, 16, 5, None), ("g16", 512, 384, 8, 16, None), ("monkey", 256, 256, 8, 3, None),
+                                                       ("monkey", 256, 256, 8, 3, 0.0), ("cube", 200, 136, 5, 4, None), ("cube", 200, 136, 5, 4, 0.0)])
+def test_batch_equals_single_frames(pkg, renderer, name, w, h, tiles_n, n, table):
+    """table = None: the library's default (dense blocks through the table kernel and, behind it, the exact kernel for what it
+    declines -- both batched); 0.0: the exact kernels only."""
     import torch
     from sgrt_amd import scene
     g = {"g64": lambda: scene.grid_scene(64), "g16": lambda: scene.grid_scene(16),
@@ -39,7 +43,8 @@ def test_batch_equals_single_frames(pkg, renderer, name, w, h, tiles_n, n):
     # reference: every frame on its own, one context
     renderer.set_gaussians(g)
     renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
-    renderer.set_table_step(0.0)
+    if table is not None:
+        renderer.set_table_step(table)
     renderer.set_shard(0, 1)
     want = []
     for c in cams:
@@ -47,7 +52,7 @@ def test_batch_equals_single_frames(pkg, renderer, name, w, h, tiles_n, n):
         renderer.tile_gaussians(tw, th, c.view)
         want.append(renderer.render(c.position, pack, want_radiance=False)[0].reshape(-1))
     st = torch.cuda.current_stream().cuda_stream
-    ctxs = make_contexts(pkg, n, g, w, h, cams[0])
+    ctxs = make_contexts(pkg, n, g, w, h, cams[0], table=table)
     try:
         # (pixels no tile covers -- 136 rows in 5 tiles of 27 -- are never written: 0 as in vrt_hip_frame's own buffer)
         fill = 0 if name == "cube" else 0x55
@@ -196,12 +201,10 @@ def test_batch_refusals(pkg, renderer):
         with pytest.raises(pkg.VrtHipError, match="differ"):
             ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
         ctxs[1].set_camera_view(w, w, cam.view)
-        for r in ctxs:
-            r.set_table_step(0.1)
-        with pytest.raises(pkg.VrtHipError, match="table"):
+        ctxs[1].set_table_step(0.1)                            # the frames of a batch share ONE table setting
+        with pytest.raises(pkg.VrtHipError, match="differ"):
             ctxs[0].frame_batch_call([ctxs[1]], 2 / 4, 2 / 4, [cam.view] * 2, [cam.position] * 2, 0)(ptrs, 0)
-        for r in ctxs:
-            r.set_table_step(0.0)
+        ctxs[1].set_table_step(ctxs[0].table_step)
         # single frames right after the refused batch (its contexts had advanced their generations for kernels that never ran)
         for r_, o_ in zip(ctxs, out):
             o_.zero_()

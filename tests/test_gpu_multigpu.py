@@ -38,7 +38,8 @@ def single_frame(pkg, r, g, cam, w, h, tiles_n, pack, table=0.0):
     ("g64", 1024, 1024, 16, 2, 0.0, 0.0),        # sparse scene: 95 % background
     ("g64", 1024, 1024, 16, 8, 47.0, 0.0),       # seen at an angle: dense cells appear
     ("monkey", 512, 512, 16, 3, 20.0, 0.0),      # dense kernel for most cells
-    ("monkey", 512, 512, 16, 2, 20.0, 0.12),     # table kernel + exact kernel behind it
+    ("monkey", 512, 512, 16, 2, 20.0, 0.05),     # table kernel (the default step) + exact kernel behind it
+    ("monkey", 512, 512, 16, 2, 20.0, 0.12),     # a coarser step: second attempts, declined blocks
     ("cube", 200, 136, 5, 3, 123.0, 0.0),        # 40 x 27-px tiles: partial cells; truncated tile size
     ("g4", 96, 96, 2, 8, 0.0, 0.0),              # more ranks than tiles
 ])
