@@ -129,7 +129,8 @@ struct vrt_hip_ctx {
     int num_cus = 256;
     float table_hx = 0.05f;      // vrt_hip_set_table_step(): requested node spacing of the table kernel; 0 = the exact kernels only
     float table_budget = 2.5e-5f; // vrt_hip_set_table_budget(): worst-case change of a ray's radiance the table kernel may cause
-    float table_adapt = 2.5f;     // the table kernel may coarsen the requested spacing by up to this factor where its estimate of the
+    float table_room = 0.9f;      // share of the budget the kernel's ESTIMATE of its bound may fill when it coarsens the spacing (VRT_HIP_TABLE_ROOM)
+    float table_adapt = 3.f;      // the table kernel may coarsen the requested spacing by up to this factor where its estimate of the
                                   // bound leaves room (VRT_HIP_TABLE_ADAPT; 1 = never)
     int dense_idle_grid = 1; // workgroups of the dense launch when nothing is expected for it (VRT_HIP_DENSE_IDLE_GRID): one
                              // 1024-thread workgroup finds a CU with 61 KB of LDS free sooner than eight do (-2 % with frames in flight)
@@ -390,7 +391,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.n_light = cnt + 1; g.light_threshold = c->lists_light; // as the lists in the buffers were built
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
-    g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
+    g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.table_room = c->table_room; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
     g.feedback = c->d_fb;
     g.dense_is_sorted = 1;
@@ -802,6 +803,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     }
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
     if (const char *e = getenv("VRT_HIP_TABLE_STEP")) { const float v = (float)atof(e); if (v >= 0.f && v <= 1.f) c->table_hx = v; }
+    if (const char *e = getenv("VRT_HIP_TABLE_ROOM")) { const float v = (float)atof(e); if (v > 0.f && v <= 10.f) c->table_room = v; }
     if (const char *e = getenv("VRT_HIP_TABLE_ADAPT")) { const float v = (float)atof(e); if (v >= 1.f && v <= 3.f) c->table_adapt = v; }
     if (const char *e = getenv("VRT_HIP_TABLE_BUDGET")) { const float v = (float)atof(e); if (v > 0.f) c->table_budget = v; }
     if (const char *e = getenv("VRT_HIP_TILE_CONES")) c->cache_cones = atoi(e) != 0;

@@ -93,6 +93,7 @@ struct CellGrid {
     // radiance the table may cause (worst-case bound, checked per ray), and the queue of the blocks it declines, which
     // the exact dense kernel works off afterwards
     float table_hx, table_budget;
+    float table_room;                // ... and the share of the budget its estimate may fill when it does (the estimate is not the bound)
     float table_adapt;               // the table kernel may choose a spacing up to this many times the requested one where its estimate
                                      // of the error bound leaves room (1 = always as requested)
     uint32_t *overflow2, *n_overflow2;

@@ -1357,7 +1357,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 for (int w = 0; w < DW; ++w) { pin_t += lds.red[0][w][lane]; pout_t += lds.red[1][w][lane]; }
                 const float est_in = 1.01f * TB_W0 * u * u * pin_t, est_out = 1.01f * TB_COUT * (u * u) * (u * u) * S_all * pout_t;
                 float kappa = 1.f;
-                const float room = 0.6f * C.table_budget;
+                const float room = C.table_room * C.table_budget;
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
                     const float k = c == 0 ? 3.f : c == 1 ? 2.5f : c == 2 ? 2.f : c == 3 ? 1.6f : 1.3f;

@@ -47,8 +47,10 @@ static const char *const HELP_MSG =
     "      --plane-arrays        upload per-pixel projection-plane points like the reference instead of generating\n"
     "                            rays in the kernel (same image, 12 more bytes per ray)\n"
     "      --cull-eps E          contributions below E are skipped (1e-9); 0 evaluates the reference's full sum\n"
-    "      --table-step S        approximate mode for dense scenes: tabulate the transmittance along each ray at 160\n"
-    "                            nodes at most S*sqrt(2)*sigma apart (0 = off; 0.12 stays within 1e-5 on the test objects)\n"
+    "      --table-step S        dense blocks tabulate the transmittance along each ray at nodes S*sqrt(2)*sigma apart\n"
+    "                            (coarser where the kernel's own error bound leaves room) and interpolate; every ray stays\n"
+    "                            within --table-budget of the exact sum or its block is shaded exactly (0.05; 0 = exact only)\n"
+    "      --table-budget B      largest worst-case change of a ray's radiance the table may cause (2.5e-5)\n"
     "      --help                this text\n";
 
 struct cmd_args_t { // main.cpp:54-184
@@ -57,7 +59,7 @@ struct cmd_args_t { // main.cpp:54-184
     char *outfile = nullptr, *infile = nullptr;
     bool use_grid = false;
     u64 thread_count = 1, nr_frames = 1, tiles = 16, mode = 8;
-    f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f, table_step = 0.f;
+    f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f, table_step = 0.05f, table_budget = 2.5e-5f;
     bool plane_arrays = false;
     u64 gpus = 1;
     cmd_args_t(int argc, char **argv)
@@ -71,7 +73,7 @@ struct cmd_args_t { // main.cpp:54-184
             { "rotation", required_argument, NULL, 'r' }, { "initial-rotation", required_argument, NULL, 'i' },
             { "camera-offset", required_argument, NULL, 'c' }, { "focal-length", required_argument, NULL, 0xfe },
             { "help", no_argument, NULL, 0xff }, { "plane-arrays", no_argument, NULL, 0xfd },
-            { "cull-eps", required_argument, NULL, 0xfc }, { "table-step", required_argument, NULL, 0xfb },
+            { "cull-eps", required_argument, NULL, 0xfc }, { "table-step", required_argument, NULL, 0xfb }, { "table-budget", required_argument, NULL, 0xf9 },
             { "gpus", required_argument, NULL, 0xfa },
             { NULL, 0, NULL, 0 }
         };
@@ -97,6 +99,7 @@ struct cmd_args_t { // main.cpp:54-184
             case 0xfd: plane_arrays = true; break;
             case 0xfc: cull_eps = strtof(optarg, NULL); break;
             case 0xfb: table_step = strtof(optarg, NULL); break;
+            case 0xf9: table_budget = strtof(optarg, NULL); break;
             case 0xfa: gpus = strtoul(optarg, NULL, 10); break;
             case 'm': mode = strtoul(optarg, NULL, 10); if (mode < 1 || mode > 8) mode = 8; break;
             default: break;
@@ -154,6 +157,7 @@ static int run_on_group(const cmd_args_t &cmd, const std::vector<vrt::gaussian_t
         chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians", ctx);
         chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options", ctx);
         chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step", ctx);
+        chk(vrt_hip_set_table_budget(ctx, cmd.table_budget), "set_table_budget", ctx);
         if (deal_frames) chk(vrt_hip_set_shard(ctx, 0, 1), "set_shard", ctx); // every member renders whole frames
     }
     const u64 width = cmd.w, height = cmd.h;
@@ -273,6 +277,7 @@ int main(int argc, char **argv)
         chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians");
         chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options");
         chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step");
+        chk(vrt_hip_set_table_budget(ctx, cmd.table_budget), "set_table_budget");
     }
 
     const u64 width = cmd.w, height = cmd.h;
