@@ -310,6 +310,8 @@ typedef struct {
     uint64_t table_declined;  /* blocks handed to the exact kernel                                           */
     uint64_t table_coarser;   /* blocks done at a coarser spacing than requested (the bound left room)       */
     uint64_t table_empty;     /* of table_blocks, blocks no Gaussian reaches (the rim of a dense cell)       */
+    uint64_t table_phase_ticks[8]; /* 10-ns ticks its workgroups spent, summed over blocks: set-up, cull, range, spacing
+                                      estimate, kink weights, table, emission, reduction                      */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

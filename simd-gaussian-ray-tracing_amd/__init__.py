@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("dense_busy_frac", C.c_double), ("table_blocks", C.c_uint64),
                 ("lane_pairs", C.c_uint64), ("dense_visits_full", C.c_uint64), ("dense_visits_zero", C.c_uint64),
                 ("dense_visits_common", C.c_uint64), ("table_nodes", C.c_uint64), ("table_retries", C.c_uint64),
-                ("table_skips", C.c_uint64), ("table_declined", C.c_uint64), ("table_coarser", C.c_uint64), ("table_empty", C.c_uint64)]
+                ("table_skips", C.c_uint64), ("table_declined", C.c_uint64), ("table_coarser", C.c_uint64), ("table_empty", C.c_uint64), ("table_phase_ticks", C.c_uint64 * 8)]
 
 
 def build(verbose=False):
@@ -437,7 +437,7 @@ class Renderer:
     def stats(self):
         s = Stats()
         self._chk(self._L.vrt_hip_get_stats(self._h, C.byref(s)), "get_stats")
-        return {k: getattr(s, k) for k, _ in Stats._fields_}
+        return {k: (list(getattr(s, k)) if k == "table_phase_ticks" else getattr(s, k)) for k, _ in Stats._fields_}
 
 
 class Group:

@@ -218,6 +218,18 @@ struct ErfEval<VRT_ERF_AS> {
         const float p2 = p * p;
         return __builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p2 * p2), x);
     }
+    // R(x) = 1 / p(|x|)^4: Erf(x) = sign(x) (1 - R(x)).  Where the sign of x is known for a whole wave the callers form
+    // E - Erf(x) without the sign transfer (a 3-source v_bfi_b32: 4.3 issue cycles, profiles/r02_valu_ops.txt).
+    __device__ __forceinline__ float R(float x) const
+    {
+        const float t = __builtin_fabsf(x);
+        float p = __builtin_fmaf(c3, t, c2);
+        p = __builtin_fmaf(p, t, c1);
+        p = __builtin_fmaf(p, t, c0);
+        p = __builtin_fmaf(p, t, 1.0f);
+        const float p2 = p * p;
+        return __builtin_amdgcn_rcpf(p2 * p2);
+    }
 };
 
 template <int ERF>

@@ -646,7 +646,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
     const TileLists t = work_lists(c);
     if (o.stats) {
-        HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 24 * sizeof(unsigned long long), st));
+        HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 32 * sizeof(unsigned long long), st));
         HIPCHK(c, hipMemsetAsync(c->d_stats.p + 8, 0xFF, sizeof(unsigned long long), st)); // running minimum
     }
     c->timeline_items = 0;
@@ -823,7 +823,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        c->d_stats.reserve(24) != hipSuccess) {
+        c->d_stats.reserve(32) != hipSuccess) {
         delete c;
         return fail(nullptr, VRT_HIP_ERR_HIP, "create: stream/event creation failed");
     }
@@ -1170,9 +1170,10 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
     if (c->stats_on) {
-        unsigned long long st[24];
+        unsigned long long st[32];
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
         c->last.table_nodes = st[16]; c->last.table_retries = st[17]; c->last.table_skips = st[18]; c->last.table_declined = st[19]; c->last.table_coarser = st[20]; c->last.table_empty = st[21];
+        for (int k = 0; k < 8; ++k) c->last.table_phase_ticks[k] = st[24 + k];
         c->last.lane_pairs = st[12];
         c->last.dense_visits_full = st[13]; c->last.dense_visits_zero = st[14]; c->last.dense_visits_common = st[15];
         c->last.dense_busy_frac = (st[11] && st[9] > st[8]) ? (double)st[10] / ((double)st[11] * (double)(st[9] - st[8])) : 0.0;

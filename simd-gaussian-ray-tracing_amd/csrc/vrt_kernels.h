@@ -137,7 +137,8 @@ struct RenderTarget {
                                // [13..15]=dense kernel: (emitter chunk, absorber) visits evaluated in full / exactly zero / exactly -2A
                                // [16]=table kernel: sum of node counts over its blocks [17]=blocks it did at the reduced spacing
                                // [18]=(absorber, wave) visits it settled by saturation [19]=blocks it declined [20]=blocks it did at a coarser spacing
-                               // than requested [21]=blocks of its queue that no Gaussian reaches   (24 words in all)
+                               // than requested [21]=blocks of its queue that no Gaussian reaches
+                               // [24..31]=table kernel: 10-ns ticks per phase, summed over blocks   (32 words in all)
     unsigned long long *timeline; // nullable diagnostics: 4 wall_clock64 stamps + the hardware id per one-wave work item (5 words)
 };
 

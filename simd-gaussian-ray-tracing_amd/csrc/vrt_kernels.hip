@@ -1117,14 +1117,32 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
     for (uint32_t c = 0; c < chunks; ++c) {
         if (c + 1 < chunks) stage(c + 1);
         const uint32_t b = c & 1u, nj = min((uint32_t)TB_CH, cnt - c * TB_CH);
+        // the next absorber's staged values are requested one iteration ahead (LDS latency behind the erf terms)
+        float nA = lds.st.A[b][0][lane], nM = lds.st.M[b][0][lane], nE = lds.st.E[b][0][lane], nR = lds.st_r[b][0];
         for (uint32_t jj = 0; jj < nj; ++jj) {
-            const float A = lds.st.A[b][jj][lane], m = lds.st.M[b][jj][lane], E = lds.st.E[b][jj][lane];
-            const float r = lds.st_r[b][jj];
+            const float A = nA, m = nM, E = nE, r = nR;
+            if (jj + 1 < nj) { nA = lds.st.A[b][jj + 1][lane]; nM = lds.st.M[b][jj + 1][lane]; nE = lds.st.E[b][jj + 1][lane]; nR = lds.st_r[b][jj + 1]; }
             const float hr = h * r;
             const float x0 = __builtin_fmaf(s_first, r, -m), x1 = __builtin_fmaf((float)(NT - 1), hr, x0);
             // saturated over the wave's whole node range on all rays: Erf = -1 (absorber behind the nodes) or +1 (in front)
             if (__all(x1 <= -SAT_M)) { common = __builtin_fmaf(A, E + 1.f, common); ++n_skip; continue; }
             if (__all(x0 >= SAT_M)) { common = __builtin_fmaf(A, E - 1.f, common); ++n_skip; continue; }
+            if constexpr (ERF == VRT_ERF_AS) {
+                // one sign over the whole range on all rays (all but the absorbers whose kink lies inside it): Erf = +-(1 - R), so
+                // E - Erf = (E - 1) + R or (E + 1) - R -- ten instructions per term instead of twelve, no sign transfer
+                if (__all(x0 >= 0.f)) {
+                    const float Em1 = E - 1.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Em1 + erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+                    continue;
+                }
+                if (__all(x1 <= 0.f)) {
+                    const float Ep1 = E + 1.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Ep1 - erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+                    continue;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
         }
@@ -1160,6 +1178,11 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
         __syncthreads();
         const uint32_t item = s_item;
         if (item >= n_items) break;
+        // phase clock (statistics runs only): thread 0 adds the time since the last stamp to stats[24 + phase]
+        unsigned long long t_last = (O.stats && tid == 0) ? wall_clock64() : 0ull;
+        auto stamp = [&](int phase) {
+            if (O.stats && tid == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&O.stats[24 + phase], t - t_last); t_last = t; }
+        };
         uint32_t cell, bi;
         if (item < n_dense16) { cell = dense_queue[item >> 4]; bi = item & 15u; }
         else { const uint32_t packed = C.overflow[item - n_dense16]; cell = packed >> 4; bi = packed & 15u; }
@@ -1190,6 +1213,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
         float co, si;
         cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
         const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
+        stamp(0);
 
         // ---- cooperative block cull, order preserving across the 16 waves (as in the exact kernel) ----
         uint32_t cnt = 0;
@@ -1219,6 +1243,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             __syncthreads();
         }
 
+        stamp(1);
         if (cnt == 0) { // nothing reaches this block (the rim of a dense cell): background
             if (wave == 0 && valid) {
                 if (O.image) O.image[out] = pack_pixel(0.f, 0.f, 0.f, 0.f, O.pack_flags);
@@ -1250,6 +1275,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             }
             __syncthreads();
         }
+        stamp(2);
         const float range = wave_max(s_hi - s_lo); // the block's longest sample range
         const float h_req = C.table_hx / r_max;    // requested spacing: table_hx in units of 1/r of the narrowest Gaussian
         ok = ok && range >= 0.f && h_req > 0.f && range < INFINITY; // (false for NaN)
@@ -1373,6 +1399,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 have_kinks = h == h_before && nseg_before == 1u; // segment 0's weights at this spacing are still in LDS
                 if (O.stats && tid == 0 && h != h_before) atomicAdd(&O.stats[20], 1ull);
             }
+            stamp(3);
             const uint32_t g0 = wave * NTsel;
             float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f, b_in = 0.f, b_out = 0.f;
 
@@ -1383,6 +1410,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 for (uint32_t g = wave; g < G; g += DW)
                     lds.s3[g][lane] = (uint8_t)fminf(floorf((float)lds.hist[g][lane] * s3_scale) + 1.f, 255.f);
                 __syncthreads(); // the weights are read: their memory becomes the table; the partial sums' memory the staging buffers
+                stamp(4);
 
                 // ---- table: wave w evaluates the nodes [w NT, (w+1) NT) of the segment against all survivors ----
                 const float s_first = __builtin_fmaf(node0 + (float)g0, h, lo);
@@ -1396,6 +1424,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
                 }
                 __syncthreads();
+                stamp(5);
 
                 // ---- emission: the emitters are dealt to the waves; X(s_ik) by 4-point Lagrange interpolation for the samples
                 //      of this segment; the error bound is accumulated beside the radiance ----
@@ -1444,6 +1473,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                     }
                 }
                 __syncthreads(); // nobody reads the staging buffers or the table any more
+                stamp(6);
             }
             lds.L[wave][lane] = make_float4(Lr, Lg, Lb, La);
             float2 *bparts = reinterpret_cast<float2 *>(&lds.tab[0][0]); // [DW][64]
@@ -1472,6 +1502,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 if (lane == 0) s_flag = all_good ? 1u : 0u;
             }
             __syncthreads();
+            stamp(7);
             done = s_flag != 0u;
             if (!done) {
                 if (attempt >= 1) { ok = false; break; }

@@ -43,4 +43,4 @@ for name, w, rot in (("teapot", 2048, 0.0), ("monkey", 4096, 0.0), ("monkey", 40
         tb = max(st["table_blocks"], 1)
         print(f"   step {step:5.3f}: {dt*1e3:8.3f} ms ({dt0/dt:4.1f}x)  max |d radiance| {d.max():.2e}  u8 steps {np.abs(ch).max()} ({(ch != 0).sum()} values)"
               f" | table blocks {st['table_blocks']} of {st['dense_blocks']} dense, declined {st['table_declined']}, second attempts {st['table_retries']},"
-              f" coarser than requested {st['table_coarser']}, nodes per block {st['table_nodes']/tb:.0f}, saturated visits {st['table_skips']:.3e}", flush=True)
+              f" phases us/block {[round(t*0.01/tb,1) for t in st['table_phase_ticks']]} coarser than requested {st['table_coarser']}, nodes per block {st['table_nodes']/tb:.0f}, saturated visits {st['table_skips']:.3e}", flush=True)
