@@ -147,6 +147,11 @@ def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
     }
 
 
+def gather_batch_frames(gather_frames, steps):
+    """Frames per RCCL gather for a run of `steps` timed steps: --gather-frames, but never more than a quarter of the run."""
+    return max(1, min(int(gather_frames), max(int(steps), 1) // 4 if steps >= 4 else 1))
+
+
 def pick_streams(n, frame_a, frame_b, fixed=()):
     """n HIP streams that overlap pairwise (and with the streams in `fixed`).  The HIP runtime runs all streams of a process
     on a handful of hardware queues (four by default; a stream gets one when it is first used), and two streams on one
@@ -197,10 +202,10 @@ def main():
     ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
     ap.add_argument("--setup-ms", type=float, default=50.0, help="untimed set-up frames before the warm-up steps, in milliseconds of wall time")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: launch every frame of a gather batch on its own (round-2 baseline)")
-    ap.add_argument("--frames-in-flight", type=int, default=0,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial "
-                         "frames; 0 (default) = 4, or 3 when fewer than 32 steps are timed (a short run is mostly filling and "
-                         "draining the pipeline: 20 steps read 30.4-31.0 us per frame with three in flight, 31.6-34.6 with four)")
+                         "frames; default 4 = one per hardware queue of the HIP runtime, whatever --steps is (round 2 took 3 for "
+                         "short runs; the other counts are measured after the timed region and reported under in_flight_sweep)")
     ap.add_argument("--parallel", choices=["tiles", "frames"], default="tiles",
                     help="N > 1: 'tiles' = one frame's tiles sharded over the ranks + gather (the headline, SURVEY 8e); 'frames' = "
                          "every rank renders whole frames of its own, no collective (the replicas-only alternative: weak scaling)")
@@ -255,7 +260,7 @@ def main():
     # (the frame rate is set by the gather there).
     solo = world == 1 or args.parallel == "frames"   # this rank renders whole frames on its own
     if args.frames_in_flight <= 0:
-        args.frames_in_flight = 4 if args.steps >= 32 else 3
+        args.frames_in_flight = 4
     nctx = max(1, args.frames_in_flight) if solo else 1
 
     def make_renderer():
@@ -299,7 +304,10 @@ def main():
     # the used prefixes to rank 0 (double-buffered against the next batch's rendering), rank 0 assembles every gathered
     # frame: background + stored cells (vrt_hip_scatter_sparse_device).  The same class runs under gloo in
     # tests/test_dist_gloo.py.
-    F = max(1, min(args.gather_frames, max(args.steps, 1)))
+    # (a short run -- the driver times 20 steps -- takes smaller batches, so that at least four of them exist and rendering,
+    # gather and assembly of different batches overlap as in the steady state: one batch of 20 would be a single
+    # un-overlapped render -> gather -> assemble chain)
+    F = gather_batch_frames(args.gather_frames, args.steps)
     if not solo:
         from sgrt_amd.sharding import SparseFrameGatherer, sparse_pixel_offset
         words = r.sparse_shard_words()
@@ -430,6 +438,57 @@ def main():
     run(n_serial, 1, serial=True)
     barrier()
     serial_ms = (time.perf_counter() - t1) / max(n_serial, 1) * 1e3
+    # What a frame loop with a MOVING camera costs (N = 1): the same workload, the view turned by 1e-4 degrees per step, so
+    # nothing a static view lets the library keep (per-origin tables, tile cones, the dense-launch report) applies: every
+    # frame sets its rays, rebuilds the cone table and runs all launches.  Same frames in flight, then serial.
+    moving = None
+    sweep = None
+    if solo and world == 1 and not args.plane_arrays:
+        poses = [scene.cli_camera(w, h, initial_rot=1e-4 * k)[0] for k in range(64)]
+        mcalls = [[r_.frame_view_call(tw, th, p_.view, p_.position, pack) for p_ in poses] for r_ in ctxs]
+
+        def run_moving(nsteps, in_flight):
+            for k in range(nsteps):
+                i = k % in_flight
+                mcalls[i][k % 64](img_ptrs[i], sps[i])
+
+        run_moving(64, nctx)
+        barrier()
+        t2 = time.perf_counter()
+        run_moving(n_serial, nctx)
+        barrier()
+        mov_ms = (time.perf_counter() - t2) / n_serial * 1e3
+        # the last frame of every context against a fresh render of its pose
+        last = {(k % nctx): k % 64 for k in range(n_serial)}
+        mov_ok = True
+        for i_, k_ in last.items():
+            r.set_camera_view(w, h, poses[k_].view)
+            r.tile_gaussians(tw, th, poses[k_].view)
+            ref_, _ = r.render(poses[k_].position, pack, want_radiance=False)
+            mov_ok = mov_ok and bool((images[i_].cpu().numpy().view(np.uint32) == ref_.reshape(-1)).all())
+        t2 = time.perf_counter()
+        run_moving(n_serial, 1)
+        barrier()
+        mov_serial_ms = (time.perf_counter() - t2) / n_serial * 1e3
+        moving = {"what": "the view turned by 1e-4 degrees per step: rays, cone table, lists and every launch per frame",
+                  "frames_in_flight": nctx, "ms_per_step": mov_ms, "value": w * h / (mov_ms * 1e-3) / 1e6,
+                  "serial_ms_per_frame": mov_serial_ms, "serial_value": w * h / (mov_serial_ms * 1e-3) / 1e6, "steps": n_serial,
+                  "frames_equal_reference": mov_ok}
+        # back to the static view of the timed region (the statistics pass and the frame check below use it)
+        for r_ in ctxs:
+            r_.set_camera_view(w, h, view)
+        run(2 * nctx)
+        barrier()
+        sweep = {}
+        for nf in range(1, nctx + 1):
+            run(4 * nf, nf)
+            barrier()
+            t2 = time.perf_counter()
+            run(n_serial, nf)
+            barrier()
+            sweep[str(nf)] = (time.perf_counter() - t2) / n_serial * 1e3
+        run(2 * nctx)   # every frame buffer holds the static frame again
+        barrier()
     r.enable_kernel_timing(1)
     run(max(50, min(args.steps, 100)), 1, serial=True)
     barrier()
@@ -475,6 +534,10 @@ def main():
         share = 1 if solo else world   # tile sharding: a rank's kernels see 1/world of the frame
         render_bytes = (sb * 64 * per_ray + 4 * st["tile_entries"] + 64 * len(g)) / share
         frame_bytes = (w * h * per_ray + 64 * len(g) + 4 * n_entries) / share
+        # the dominant kernel's duration is that of the SERIAL launch (frames in flight stretch a launch: it shares the GPU with
+        # the other contexts' kernels, and is then no component of the step); the overlapped figure is kept beside it
+        kernel_ms_overlapped = kernel_ms
+        kernel_ms = kt["render_serial_ms"] if (solo and kt["render_serial_ms"] > 0) else kernel_ms
         render_gbs = render_bytes / (kernel_ms * 1e-3) / 1e9
         # the whole frame: wall time per step of the timed region (one rank: nothing but the launch sequence is in it)
         frame_ms = ms_per_step if solo else kt["lists_ms"] + kt["render_ms"] + kt["dense_ms"]
@@ -544,13 +607,16 @@ def main():
                        "shard_transport": (None if solo else {"format": "sparse: 32x32-px cells that hold something", "bytes_per_frame":
                                            fg.bytes_moved / max(1, fg.frames_moved), "compact_shards_would_be": (world - 1) * w * h * 4 // world,
                                            "batches_gathered_twice": fg.regathered}),
+                       "frames_per_gather": (None if solo else F),
+                       "gather_batches_in_timed_region": (None if solo else (args.steps + F - 1) // F),
                        "frames_in_flight": nctx,
                        "stream_probe_us_per_frame": stream_probe,
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": render_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_from": (valu.get("from") if traffic is not None else None),
-                         "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": render_bytes,
+                         "kernel": "render_kernel<VCL,AS,4>", "kernel_ms": kernel_ms, "kernel_ms_with_frames_in_flight": kernel_ms_overlapped,
+                         "algorithmic_bytes": render_bytes,
                          # (an event pair with nothing between reads ~5 us on this stack -- measured in round 1 on an empty
                          # launch slot; rocprofv3's kernel durations under profiles/ are the event figures minus that)
                          # strictly serial frames, after the timed region: four events per frame
@@ -560,10 +626,12 @@ def main():
                                    "frac": frame_gbs / HBM_PEAK_GBS, "traffic": traffic_frame},
                          "note": "the path is VALU/transcendental-bound, not HBM-bound (SURVEY 7 hard part 4): see valu; "
                                  "traffic = WRITE_SIZE + raw FETCH_SIZE of separate PMC passes (profiles/); with several frames "
-                                 "in flight kernel_ms is the duration of a launch that shares the GPU with the other "
-                                 "context's kernels (launch_sequence_ms: the same kernels alone)"},
+                                 "in flight a launch shares the GPU with the other contexts' kernels and lasts longer "
+                                 "(kernel_ms_with_frames_in_flight); kernel_ms is the serial launch, a component of ms_per_frame"},
             # the same loop with one context: frame k+1 starts when frame k is done
             "serial": {"frames_in_flight": 1, "ms_per_step": serial_ms, "value": w * h / (serial_ms * 1e-3) / 1e6, "steps": n_serial},
+            "moving_camera": moving,
+            "in_flight_sweep_ms_per_step": sweep,
             "valu": {**valu, "blocks": st["blocks"], "shaded_blocks": st["shaded_blocks"], "dense_blocks": st["dense_blocks"],
                      "mean_cell_list": st["tile_entries"] / sb, "mean_block_list": st["list_entries"] / sb,
                      "mean_ray_list": st["lane_entries"] / (sb * 64), "mean_block_longest_ray_list": st["lane_max_entries"] / sb,

@@ -149,6 +149,13 @@ void vrt_hip_mat4_inverse(const float m[16], float out[16]);
  * block are skipped for that block (0 disables culling and reproduces the reference's
  * full O(5 N^2) sum).  Defaults: VRT_EXP_VCL, VRT_ERF_AS, cull_eps = 1e-9. */
 int vrt_hip_set_options(vrt_hip_ctx *ctx, int exp_kind, int erf_kind, float cull_eps);
+/* Mirror contexts (one frame needs one context: a batch of n frames needs n of them with the same scene): copies scene,
+ * Exp / Erf / cull options, table settings and shard from src to dst (same device; device-to-device copies).  Rays, tiles
+ * and statistics settings are not copied.  vrt_hip_state_generation() changes whenever one of the copied things changes. */
+int vrt_hip_copy_state(vrt_hip_ctx *dst, const vrt_hip_ctx *src);
+uint64_t vrt_hip_state_generation(const vrt_hip_ctx *ctx);
+/* Image size of the rays last set (VRT_HIP_ERR_INVALID before vrt_hip_set_plane / set_camera / set_camera_view). */
+int vrt_hip_get_image_size(const vrt_hip_ctx *ctx, uint32_t *w, uint32_t *h);
 
 /* -------- render: replaces render_image / simd_render_image (rt.h:227-404) ------------- */
 /* Renders the current scene/tiles/rays.  image_out: w*h u32 (nullable); radiance_out:
@@ -248,6 +255,20 @@ int vrt_hip_group_frame(vrt_hip_group *g, float tw, float th, const float view[1
 /* The assembled frame on member 0's device (valid until the next group_frame), for callers that keep it on the GPU. */
 const uint32_t *vrt_hip_group_image_device(const vrt_hip_group *g);
 int vrt_hip_group_sync(vrt_hip_group *g);
+/* n frames of an animation tile-sharded over the members with ONE launch of each kernel per member and ONE assembly launch
+ * on member 0 (vrt_hip_frame_batch_device + vrt_hip_scatter_sparse_batch_device): the frame loop of main.cpp:257-335 with
+ * the orbit's next n cameras handed over at once.  A member's shard of a sparse frame is a few microseconds of work behind
+ * three dependent launches: frame by frame the group is launch-bound and slower than one GPU; in batches the launches are
+ * paid once per n frames.  views: 16 n floats, origins: 3 n floats; every frame is rendered with in-kernel rays of its view
+ * matrix at the image size of member 0's rays (vrt_hip_set_camera_view / set_plane must have been called once).  The group
+ * keeps n - 1 mirror contexts per member (scene, options and table settings copied from the member's own context whenever
+ * vrt_hip_state_generation() says they changed).  images_out: NULL, or n host pointers (each NULL or w*h u32); returns when
+ * the frames are complete if wait != 0 or any image is wanted.  Each frame equals vrt_hip_group_frame's, bit for bit.
+ * n <= 64. */
+int vrt_hip_group_frame_batch(vrt_hip_group *g, int n, float tw, float th, const float *views, const float *origins,
+                              int pack_flags, uint32_t *const *images_out, int wait);
+/* Frame f of the last batch on member 0's device (valid until the next batch). */
+const uint32_t *vrt_hip_group_batch_image_device(const vrt_hip_group *g, int f);
 
 /* -------- point queries: replace transmittance / radiance (rt.h:32-54, 146-223) ----------- */
 /* T_out[k] = transmittance<Exp,Erf>(o, n, s[k], all Gaussians of the scene), rt.h:32-54. */
@@ -312,6 +333,8 @@ typedef struct {
     uint64_t table_empty;     /* of table_blocks, blocks no Gaussian reaches (the rim of a dense cell)       */
     uint64_t table_phase_ticks[8]; /* 10-ns ticks its workgroups spent, summed over blocks: set-up, cull, range, spacing
                                       estimate, kink weights, table, emission, reduction                      */
+    uint64_t dense_launch_skips; /* frames of this context whose dense launch was left out (a frame of exactly the same state had
+                                    reported that there is nothing for it); counted since the context was created */
 } vrt_hip_stats;
 int vrt_hip_get_stats(vrt_hip_ctx *ctx, vrt_hip_stats *out);
 /* Enables per-block statistics collection (small atomics; off by default). */

@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("dense_busy_frac", C.c_double), ("table_blocks", C.c_uint64),
                 ("lane_pairs", C.c_uint64), ("dense_visits_full", C.c_uint64), ("dense_visits_zero", C.c_uint64),
                 ("dense_visits_common", C.c_uint64), ("table_nodes", C.c_uint64), ("table_retries", C.c_uint64),
-                ("table_skips", C.c_uint64), ("table_declined", C.c_uint64), ("table_coarser", C.c_uint64), ("table_empty", C.c_uint64), ("table_phase_ticks", C.c_uint64 * 8)]
+                ("table_skips", C.c_uint64), ("table_declined", C.c_uint64), ("table_coarser", C.c_uint64), ("table_empty", C.c_uint64), ("table_phase_ticks", C.c_uint64 * 8), ("dense_launch_skips", C.c_uint64)]
 
 
 def build(verbose=False):
@@ -94,6 +94,11 @@ SYMBOLS = {
     "vrt_hip_group_frame": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _u32p, C.c_int]),
     "vrt_hip_group_image_device": (_vp, [_vp]),
     "vrt_hip_group_sync": (C.c_int, [_vp]),
+    "vrt_hip_group_frame_batch": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, _f32p, _f32p, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
+    "vrt_hip_group_batch_image_device": (_vp, [_vp, C.c_int]),
+    "vrt_hip_copy_state": (C.c_int, [_vp, _vp]),
+    "vrt_hip_state_generation": (C.c_uint64, [_vp]),
+    "vrt_hip_get_image_size": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vrt_hip_transmittance": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_size_t, _f32p]),
     "vrt_hip_transmittance_rays": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p, _f32p]),
     "vrt_hip_radiance": (C.c_int, [_vp, C.c_size_t, _f32p, _f32p, _f32p]),
@@ -276,6 +281,22 @@ class Renderer:
 
         def call(d_out, stream=0, _keep=(v, o)):
             rc = fn(h, tw, th, vp, op, pack, d_out, shard, stream or None)
+            if rc != 0:
+                self._chk(rc, "frame_device")
+        return call
+
+    def frame_view_call(self, tw, th, view, origin, pack):
+        """Like frame_call for a frame loop whose camera MOVES: sets the in-kernel rays of `view` (vrt_hip_set_camera_view)
+        and renders the frame, two C calls behind one pre-marshalled Python call: returns f(d_out, stream)."""
+        v = np.ascontiguousarray(view, np.float32).ravel().copy()
+        o = _f3(origin).copy()
+        setv, fn, h, vp, op = self._L.vrt_hip_set_camera_view, self._L.vrt_hip_frame_device, self._h, _fp(v), _fp(o)
+        tw, th, pack, w_, h_ = float(tw), float(th), int(pack), int(self.w), int(self.h)
+
+        def call(d_out, stream=0, _keep=(v, o)):
+            rc = setv(h, w_, h_, vp)
+            if rc == 0:
+                rc = fn(h, tw, th, vp, op, pack, d_out, 0, stream or None)
             if rc != 0:
                 self._chk(rc, "frame_device")
         return call
@@ -463,6 +484,20 @@ class Group:
         if rc != 0:
             raise VrtHipError(f"group_frame failed ({rc}): {self._L.vrt_hip_group_last_error(self._g).decode()}")
         return img.reshape(h, w) if want_image else None
+
+    def frame_batch(self, tw, th, views, origins, pack, want_images=True):
+        """vrt_hip_group_frame_batch: len(views) frames with one launch of each kernel per member and one assembly launch;
+        returns the images [n, h, w] (or None)."""
+        n = len(views)
+        w, h = self.members[0].w, self.members[0].h
+        v = np.ascontiguousarray(np.asarray(views, np.float32).reshape(n, 16))
+        o = np.ascontiguousarray(np.asarray(origins, np.float32).reshape(n, 3))
+        imgs = np.zeros((n, h, w), np.uint32) if want_images else None
+        ptrs = (C.c_void_p * n)(*[imgs[i].ctypes.data for i in range(n)]) if want_images else None
+        rc = self._L.vrt_hip_group_frame_batch(self._g, n, float(tw), float(th), _fp(v), _fp(o), int(pack), ptrs, 1)
+        if rc != 0:
+            raise VrtHipError(f"group_frame_batch failed ({rc}): {self._L.vrt_hip_group_last_error(self._g).decode()}")
+        return imgs
 
     def sync(self):
         rc = self._L.vrt_hip_group_sync(self._g)

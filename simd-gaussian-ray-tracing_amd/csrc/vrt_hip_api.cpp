@@ -56,6 +56,9 @@ struct vrt_hip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
 
+    // counts every change of scene, options or table settings (vrt_hip_state_generation): a holder of mirrored contexts
+    // (vrt_hip_group's batch lanes) sees when they are out of date
+    uint64_t state_gen = 1;
     // scene (static SoA copy kept so options can be re-applied)
     uint32_t n = 0;
     DevBuf<float> soa[9]; // mu_x mu_y mu_z ar ag ab aa sigma mag
@@ -689,6 +692,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         const uint32_t seen = c->h_fb[3]; // read first: what is read after it is at least as new
         no_dense_work = (int32_t)(seen - c->reset_seq) >= 1 && (int32_t)(seen - c->cam_seq) >= 1 && c->h_fb[0] == 0 && c->h_fb[2] == 0;
     }
+    if (no_dense_work) ++c->last.dense_launch_skips;
     CellGrid cg = cell_grid(c);
     cg.dense_is_sorted = expect_dense ? 1 : 0;
     cg.frame_seq = ++c->frame_seq;
@@ -875,6 +879,7 @@ int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const flo
     }
     c->has_alpha = aa != nullptr;
     c->n = (uint32_t)n;
+    ++c->state_gen;
     c->reset_seq = c->frame_seq;
     c->tables_dirty = true;
     c->lists_dirty = true;
@@ -906,6 +911,38 @@ int vrt_hip_set_gaussians_aos(vrt_hip_ctx *c, size_t n, const void *gaussians)
                                  soa[5].data(), soa[6].data(), soa[7].data(), soa[8].data());
 }
 
+uint64_t vrt_hip_state_generation(const vrt_hip_ctx *c) { return c ? c->state_gen : 0; }
+
+int vrt_hip_get_image_size(const vrt_hip_ctx *c, uint32_t *w, uint32_t *h)
+{
+    if (!c || !c->rays_set) return VRT_HIP_ERR_INVALID;
+    if (w) *w = c->w;
+    if (h) *h = c->h;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_copy_state(vrt_hip_ctx *dst, const vrt_hip_ctx *src)
+{
+    if (!dst || !src || dst == src) return VRT_HIP_ERR_INVALID;
+    if (dst->device != src->device) return fail(dst, VRT_HIP_ERR_INVALID, "copy_state: the contexts live on different devices");
+    HIPCHK(dst, hipSetDevice(dst->device));
+    { int rc = quiesce(dst); if (rc) return rc; }
+    HIPCHK(dst, hipStreamSynchronize(src->stream)); // uploads of the source are synchronous, its table build runs on its stream
+    for (int i = 0; i < 9; ++i) {
+        HIPCHK(dst, dst->soa[i].reserve(src->n));
+        if (src->n && src->soa[i].p) HIPCHK(dst, hipMemcpy(dst->soa[i].p, src->soa[i].p, (size_t)src->n * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    dst->has_alpha = src->has_alpha; dst->n = src->n;
+    dst->exp_kind = src->exp_kind; dst->erf_kind = src->erf_kind; dst->cull_eps = src->cull_eps;
+    dst->table_hx = src->table_hx; dst->table_budget = src->table_budget; dst->table_adapt = src->table_adapt; dst->table_room = src->table_room;
+    dst->rank = src->rank; dst->world = src->world;
+    dst->tables_dirty = true; dst->lists_dirty = true; dst->shard_dirty = true; dst->ref_valid = false;
+    dst->reset_seq = dst->frame_seq;
+    if (dst->tile_mode == TILES_HOST) { dst->tile_mode = TILES_NONE; dst->tw = dst->th = 2.f; dst->tiles_w = dst->tiles_h = 1; }
+    ++dst->state_gen;
+    return VRT_HIP_OK;
+}
+
 int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_eps)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
@@ -917,6 +954,7 @@ int vrt_hip_set_options(vrt_hip_ctx *c, int exp_kind, int erf_kind, float cull_e
     if (exp_kind != c->exp_kind || cull_eps != c->cull_eps) c->tables_dirty = true;
     if (exp_kind != c->exp_kind || erf_kind != c->erf_kind || cull_eps != c->cull_eps) c->reset_seq = c->frame_seq;
     c->exp_kind = exp_kind; c->erf_kind = erf_kind; c->cull_eps = cull_eps;
+    ++c->state_gen;
     return VRT_HIP_OK;
 }
 
@@ -926,6 +964,7 @@ int vrt_hip_set_table_step(vrt_hip_ctx *c, float hx)
     if (!(hx >= 0.f) || hx > 1.f) return fail(c, VRT_HIP_ERR_INVALID, "set_table_step: step must be in [0, 1]");
     if (hx != c->table_hx) { c->reset_seq = c->frame_seq; c->lists_dirty = true; }
     c->table_hx = hx;
+    ++c->state_gen;
     return VRT_HIP_OK;
 }
 
@@ -935,6 +974,7 @@ int vrt_hip_set_table_budget(vrt_hip_ctx *c, float budget)
     if (!(budget > 0.f)) return fail(c, VRT_HIP_ERR_INVALID, "set_table_budget: the budget must be positive (INFINITY = unchecked)");
     if (budget != c->table_budget) c->reset_seq = c->frame_seq;
     c->table_budget = budget;
+    ++c->state_gen;
     return VRT_HIP_OK;
 }
 

@@ -28,10 +28,19 @@ struct vrt_hip_group {
         size_t shard_words = 0;
         uint32_t *staged = nullptr;      // copy on member 0's device when member 0 cannot read `shard` directly
         bool peer_ok = true;
+        // frame batches: lanes[f] renders frame f of a batch (lanes[0] = ctx; the others mirror its scene and options)
+        std::vector<vrt_hip_ctx *> lanes;
+        uint64_t mirrored_gen = 0;       // vrt_hip_state_generation(ctx) the mirrors were copied at
+        uint32_t *bshard = nullptr;      // the batch's sparse shards, frame f at bshard + f * bwords
+        size_t bwords = 0;               // words per frame
+        int bframes = 0;                 // frames the buffer holds
+        uint32_t *bstaged = nullptr;
     };
     std::vector<Member> m;
     uint32_t *image = nullptr;           // assembled frame, member 0's device
     size_t image_px = 0;
+    std::vector<uint32_t *> bimages;     // assembled frames of the last batch, member 0's device
+    size_t bimage_px = 0;
     hipEvent_t assembled = nullptr;      // the previous frame has been assembled: shard buffers may be overwritten
     bool have_assembled = false;
     std::string err;
@@ -111,11 +120,15 @@ void vrt_hip_group_destroy(vrt_hip_group *g)
         (void)hipSetDevice(g->m[0].device);
         if (g->image) (void)hipFree(g->image);
         for (auto &mb : g->m) if (mb.staged) (void)hipFree(mb.staged);
+        for (auto &mb : g->m) if (mb.bstaged) (void)hipFree(mb.bstaged);
+        for (auto p : g->bimages) if (p) (void)hipFree(p);
         if (g->assembled) (void)hipEventDestroy(g->assembled);
     }
     for (auto &mb : g->m) {
         (void)hipSetDevice(mb.device);
         if (mb.shard) (void)hipFree(mb.shard);
+        if (mb.bshard) (void)hipFree(mb.bshard);
+        for (size_t k = 1; k < mb.lanes.size(); ++k) if (mb.lanes[k]) vrt_hip_destroy(mb.lanes[k]);
         if (mb.done) (void)hipEventDestroy(mb.done);
         if (mb.stream) (void)hipStreamDestroy(mb.stream);
         if (mb.ctx) vrt_hip_destroy(mb.ctx);
@@ -203,6 +216,103 @@ int vrt_hip_group_frame(vrt_hip_group *g, float tw, float th, const float view[1
     if (image_out) GCHK(g, hipMemcpyAsync(image_out, g->image, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, root.stream));
     if (image_out || wait) GCHK(g, hipStreamSynchronize(root.stream));
     return VRT_HIP_OK;
+}
+
+int vrt_hip_group_frame_batch(vrt_hip_group *g, int nf, float tw, float th, const float *views, const float *origins,
+                              int pack_flags, uint32_t *const *images_out, int wait)
+{
+    if (!g || !views || !origins) return VRT_HIP_ERR_INVALID;
+    if (nf < 1 || nf > 64) return gfail(g, VRT_HIP_ERR_INVALID, "group_frame_batch: 1..64 frames per batch");
+    const int n = (int)g->m.size();
+    uint32_t w = 0, h = 0;
+    if (vrt_hip_get_image_size(g->m[0].ctx, &w, &h) != VRT_HIP_OK)
+        return gfail(g, VRT_HIP_ERR_INVALID, "group_frame_batch: set the rays of member 0 once first (vrt_hip_set_camera_view / set_plane): the image size");
+    // ---- every member: mirrors up to date, rays of every frame, shard buffer, one batch of launches ----
+    for (int i = 0; i < n; ++i) {
+        auto &mb = g->m[i];
+        GCHK(g, hipSetDevice(mb.device));
+        if (mb.lanes.empty()) mb.lanes.push_back(mb.ctx);
+        const uint64_t gen = vrt_hip_state_generation(mb.ctx);
+        while ((int)mb.lanes.size() < nf) {
+            vrt_hip_ctx *c = nullptr;
+            const int rc = vrt_hip_create(mb.device, &c);
+            if (rc != VRT_HIP_OK) return gfail(g, rc, std::string("group_frame_batch: ") + vrt_hip_last_error(nullptr));
+            mb.lanes.push_back(c);
+            mb.mirrored_gen = 0; // the new lane has nothing yet
+        }
+        if (mb.mirrored_gen != gen) {
+            for (size_t k = 1; k < mb.lanes.size(); ++k) {
+                const int rc = vrt_hip_copy_state(mb.lanes[k], mb.ctx);
+                if (rc != VRT_HIP_OK) return gfail(g, rc, std::string("group_frame_batch: member ") + std::to_string(i) + ": " + vrt_hip_last_error(mb.lanes[k]));
+            }
+            mb.mirrored_gen = gen;
+        }
+        for (int f = 0; f < nf; ++f) {
+            int rc = vrt_hip_set_camera_view(mb.lanes[f], w, h, views + 16 * (size_t)f);
+            // the tile grid decides the shard capacity: set it before sizing the buffer
+            if (rc == VRT_HIP_OK && f == 0) rc = vrt_hip_tile_gaussians_device(mb.lanes[0], tw, th, views, mb.stream);
+            if (rc != VRT_HIP_OK) return gfail(g, rc, std::string("group_frame_batch: member ") + std::to_string(i) + ": " + vrt_hip_last_error(mb.lanes[f]));
+        }
+        const size_t words = vrt_hip_sparse_shard_words(mb.lanes[0]);
+        if (!words) return gfail(g, VRT_HIP_ERR_INVALID, "group_frame_batch: no shard geometry");
+        if (words != mb.bwords || nf > mb.bframes) {
+            GCHK(g, hipStreamSynchronize(mb.stream));
+            if (g->have_assembled) GCHK(g, hipEventSynchronize(g->assembled)); // member 0 may still be reading the old buffer
+            if (mb.bshard) (void)hipFree(mb.bshard);
+            mb.bshard = nullptr; mb.bwords = 0; mb.bframes = 0;
+            GCHK(g, hipMalloc((void **)&mb.bshard, words * (size_t)nf * sizeof(uint32_t)));
+            mb.bwords = words; mb.bframes = nf;
+            if (mb.bstaged) { (void)hipSetDevice(g->m[0].device); (void)hipFree(mb.bstaged); mb.bstaged = nullptr; (void)hipSetDevice(mb.device); }
+        }
+        if (g->have_assembled) GCHK(g, hipStreamWaitEvent(mb.stream, g->assembled, 0)); // the previous assembly still reads the shards
+        std::vector<uint32_t *> outs(nf);
+        for (int f = 0; f < nf; ++f) outs[f] = mb.bshard + (size_t)f * mb.bwords;
+        const int rc = vrt_hip_frame_batch_device(mb.lanes.data(), nf, tw, th, views, origins, pack_flags, outs.data(), 2 /* sparse shards */, mb.stream);
+        if (rc != VRT_HIP_OK) return gfail(g, rc, std::string("group_frame_batch: member ") + std::to_string(i) + ": " + vrt_hip_last_error(mb.lanes[0]));
+        GCHK(g, hipEventRecord(mb.done, mb.stream));
+    }
+    // ---- member 0 assembles all frames with one launch ----
+    auto &root = g->m[0];
+    GCHK(g, hipSetDevice(root.device));
+    std::vector<const uint32_t *> ptrs(n);
+    for (int i = 0; i < n; ++i) {
+        auto &mb = g->m[i];
+        if (i) GCHK(g, hipStreamWaitEvent(root.stream, mb.done, 0));
+        if (mb.device == root.device || mb.peer_ok) {
+            ptrs[i] = mb.bshard;
+        } else { // no peer access: the whole batch buffer is copied across
+            if (!mb.bstaged) GCHK(g, hipMalloc((void **)&mb.bstaged, mb.bwords * (size_t)mb.bframes * sizeof(uint32_t)));
+            GCHK(g, hipMemcpyPeerAsync(mb.bstaged, root.device, mb.bshard, mb.device, mb.bwords * (size_t)nf * sizeof(uint32_t), root.stream));
+            ptrs[i] = mb.bstaged;
+        }
+    }
+    const size_t npix = (size_t)w * h;
+    if (npix != g->bimage_px || (int)g->bimages.size() < nf) {
+        GCHK(g, hipStreamSynchronize(root.stream));
+        if (npix != g->bimage_px) { for (auto p : g->bimages) if (p) (void)hipFree(p); g->bimages.clear(); }
+        while ((int)g->bimages.size() < nf) {
+            uint32_t *p = nullptr;
+            GCHK(g, hipMalloc((void **)&p, npix * sizeof(uint32_t)));
+            g->bimages.push_back(p);
+        }
+        g->bimage_px = npix;
+    }
+    // the group's own buffers, written by nothing but this call: retained assembly (only cells that went dark are reset)
+    const int rc = vrt_hip_scatter_sparse_batch_device(root.ctx, ptrs.data(), n, g->m[0].bwords, nf, pack_flags, g->bimages.data(), 1, root.stream);
+    if (rc != VRT_HIP_OK) return gfail(g, rc, std::string("group_frame_batch: assemble: ") + vrt_hip_last_error(root.ctx));
+    GCHK(g, hipEventRecord(g->assembled, root.stream));
+    g->have_assembled = true;
+    bool any = false;
+    if (images_out)
+        for (int f = 0; f < nf; ++f)
+            if (images_out[f]) { GCHK(g, hipMemcpyAsync(images_out[f], g->bimages[f], npix * sizeof(uint32_t), hipMemcpyDeviceToHost, root.stream)); any = true; }
+    if (any || wait) GCHK(g, hipStreamSynchronize(root.stream));
+    return VRT_HIP_OK;
+}
+
+const uint32_t *vrt_hip_group_batch_image_device(const vrt_hip_group *g, int f)
+{
+    return (g && f >= 0 && f < (int)g->bimages.size()) ? g->bimages[f] : nullptr;
 }
 
 int vrt_hip_group_sync(vrt_hip_group *g)

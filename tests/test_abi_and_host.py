@@ -162,3 +162,17 @@ def test_shard_table_partitions_the_frame(pkg):
             o[tab[r]] = r
         load = np.bincount(o.reshape(16, 16)[6:10, 6:10].ravel(), weights=cells.ravel(), minlength=world)
         assert load.max() == load.min()
+
+
+def test_bench_gather_batches_of_a_short_run():
+    """bench.py, N > 1: the driver times 20 steps; a gather batch must then be a fraction of the run (round-2 verdict: one
+    batch of 20 was a single un-overlapped render -> gather -> assemble chain)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for steps in (4, 12, 20, 40, 100, 127):
+        F = bench.gather_batch_frames(32, steps)
+        assert 1 <= F <= 32 and (steps + F - 1) // F >= 4, (steps, F)
+    assert bench.gather_batch_frames(32, 400) == 32 and bench.gather_batch_frames(32, 20) == 5
+    assert bench.gather_batch_frames(32, 1) == 1 and bench.gather_batch_frames(4, 400) == 4

@@ -12,7 +12,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("steps,in_flight", [(20, 3), (40, 4)])
+@pytest.mark.parametrize("steps,in_flight", [(20, 4), (40, 4)])
 def test_bench_line(tmp_path, steps, in_flight):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "3", "--setup-ms", "5"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
@@ -41,5 +41,14 @@ def test_bench_line(tmp_path, steps, in_flight):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    # the dominant kernel's duration is that of the serial launch: a component of what one caller waits for a frame
+    assert 0 < r["kernel_ms"] <= d["ms_per_frame"] and r["kernel_ms_with_frames_in_flight"] > 0
     v = d["valu"]
     assert 0 < v["algorithmic"]["frac_of_frame_time"] < 1
+    # a frame loop whose camera moves: nothing memoised; slower than the static view, same images as fresh renders
+    m = d["moving_camera"]
+    assert m["frames_equal_reference"] is True and m["frames_in_flight"] == in_flight
+    assert d["ms_per_step"] * 0.8 < m["ms_per_step"] < 0.2 and d["ms_per_frame"] * 0.8 < m["serial_ms_per_frame"] < 0.3
+    assert abs(m["value"] - 2048 * 2048 / (m["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * m["value"]
+    sw = d["in_flight_sweep_ms_per_step"]
+    assert sorted(sw) == [str(k) for k in range(1, in_flight + 1)] and all(0 < t < 0.2 for t in sw.values())

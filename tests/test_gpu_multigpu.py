@@ -214,6 +214,65 @@ def test_group_frames_on_one_device(pkg, renderer):
             grp.close()
 
 
+@pytest.mark.parametrize("scene_name,w,n_members", [("g64", 768, 3), ("monkey", 256, 2)])
+def test_group_frame_batches_on_one_device(pkg, renderer, scene_name, w, n_members):
+    """vrt_hip_group_frame_batch: the orbit's next cameras handed over at once -- one launch of each kernel per member and
+    one assembly launch per batch.  Every frame equals the single-context frame, bit for bit: batches back to back (the
+    retained frame buffers), a shorter batch, a scene change in between (the mirror contexts follow the member's own
+    context), and a single group_frame afterwards."""
+    from sgrt_amd import scene
+    h = w
+    g = scene.grid_scene(64) if scene_name == "g64" else scene.read_obj(os.path.join(OBJ, scene_name + ".obj"))
+    g2 = scene.grid_scene(16)
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    cams = [scene.cli_camera(w, h, initial_rot=11.0 * k)[0] for k in range(7)]
+    want = [single_frame(pkg, renderer, g, c, w, h, 16, pack, table=pkg.TABLE_STEP_DEFAULT) for c in cams]
+    want2 = [single_frame(pkg, renderer, g2, c, w, h, 16, pack, table=pkg.TABLE_STEP_DEFAULT) for c in cams[:3]]
+    grp = pkg.Group([0] * n_members)
+    try:
+        for m in grp.members:
+            m.set_gaussians(g)
+            m.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+            m.set_camera_view(w, h, cams[0].view)
+        for lo, hi in ((0, 4), (4, 7), (1, 3)):
+            got = grp.frame_batch(2 / 16, 2 / 16, [c.view for c in cams[lo:hi]], [c.position for c in cams[lo:hi]], pack)
+            for k in range(lo, hi):
+                np.testing.assert_array_equal(got[k - lo], want[k], err_msg=f"frames {lo}..{hi}: frame {k}")
+        for m in grp.members:
+            m.set_gaussians(g2)
+        got = grp.frame_batch(2 / 16, 2 / 16, [c.view for c in cams[:3]], [c.position for c in cams[:3]], pack)
+        for k in range(3):
+            np.testing.assert_array_equal(got[k], want2[k], err_msg=f"after the scene change: frame {k}")
+        for m in grp.members:
+            m.set_camera_view(w, h, cams[2].view)
+        np.testing.assert_array_equal(grp.frame(2 / 16, 2 / 16, cams[2].view, cams[2].position, pack), want2[2])
+    finally:
+        grp.close()
+
+
+def test_group_frames_survive_a_resize_between_unwaited_frames(pkg, renderer):
+    """Round-2 advisor: the group frees a member's shard buffer when the image grows; the previous frame's assembly on
+    member 0's stream may still be reading it when that frame was not waited for."""
+    from sgrt_amd import scene
+    g = scene.grid_scene(64)
+    pack = pkg.PACK_ROUND | pkg.ALPHA_COMPUTED
+    grp = pkg.Group([0, 0])
+    try:
+        for m in grp.members:
+            m.set_gaussians(g)
+            m.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+        for w, tiles_n in ((512, 16), (1024, 16), (1024, 8), (2048, 16), (256, 4)):
+            cam = scene.cli_camera(w, w, initial_rot=20.0)[0]
+            want = single_frame(pkg, renderer, g, cam, w, w, tiles_n, pack, table=pkg.TABLE_STEP_DEFAULT)
+            for m in grp.members:
+                m.set_camera_view(w, w, cam.view)
+            grp.frame(2 / tiles_n, 2 / tiles_n, cam.view, cam.position, pack, want_image=False, wait=False)
+            grp.frame(2 / tiles_n, 2 / tiles_n, cam.view, cam.position, pack, want_image=False, wait=False)
+            np.testing.assert_array_equal(grp.frame(2 / tiles_n, 2 / tiles_n, cam.view, cam.position, pack), want, err_msg=f"{w} px, {tiles_n} tiles")
+    finally:
+        grp.close()
+
+
 def test_cli_gpus_flag(tmp_path):
     """--gpus 2 with both members on GPU 0: the tile-sharded single frame writes the PNG one GPU writes; the animation
     without output deals whole frames to the members and prints the average."""
@@ -232,6 +291,15 @@ def test_cli_gpus_flag(tmp_path):
     q = subprocess.run([exe, "-g", "8", "-w", "128", "-q", "--gpus", "2", "--frames", "3", "-o", "f.png"], cwd=tmp_path, capture_output=True,
                        text=True, timeout=300, env=env)
     assert q.returncode == 0 and all((tmp_path / f"f_{k}.png").exists() for k in (1, 2, 3)), q.stderr
+    # an orbit that writes its frames goes through the group in batches (vrt_hip_group_frame_batch): the frames one GPU writes,
+    # with 4 members on one device and batches of 5 (the last one shorter)
+    env4 = dict(os.environ, VRT_HIP_DEVICES="0,0,0,0", VRT_CLI_GROUP_BATCH="5")
+    a = subprocess.run([exe, "-g", "64", "-w", "512", "-q", "--frames", "12", "-r", "90", "-o", "s.png"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    b = subprocess.run([exe, "-g", "64", "-w", "512", "-q", "--frames", "12", "-r", "90", "--gpus", "4", "-o", "m.png"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300, env=env4)
+    assert a.returncode == 0 and b.returncode == 0 and "AVG. TIME: " in b.stdout and "(12 frames)" in b.stdout, a.stderr + b.stderr
+    for k in range(1, 13):
+        np.testing.assert_array_equal(np.array(Image.open(tmp_path / f"s_{k}.png")), np.array(Image.open(tmp_path / f"m_{k}.png")), err_msg=f"frame {k}")
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
@@ -239,11 +307,13 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     the assembled frame must equal the single-GPU frame (bench.py checks it and reports it in its JSON line)."""
     env = dict(os.environ, VRT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--gather-frames", "4",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",   # what the driver times
            "--width", "1024", "--no-cpu-baseline"]
     p = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["frame_equals_single_gpu_frame"] is True
+    # a short run takes smaller gather batches: rendering, gather and assembly of different batches overlap as in a long one
+    assert res["config"]["gather_batches_in_timed_region"] >= 3 and res["config"]["frames_per_gather"] == 5
     assert res["config"]["shard_transport"]["bytes_per_frame"] < 0.25 * 1024 * 1024 * 4

@@ -696,6 +696,17 @@ def test_dense_launch_is_left_out_only_while_nothing_changed(pkg, oracle, render
         renderer.enable_stats(False)
         return img.reshape(-1), dense
 
+    def fresh_tiles(g, cam, tiles_n):
+        renderer.set_gaussians(g)
+        renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+        renderer.set_camera_view(w, h, cam.view)
+        renderer.tile_gaussians(2 / tiles_n, 2 / tiles_n, cam.view)
+        renderer.enable_stats(True)
+        img = renderer.render(cam.position, pack, want_radiance=False)[0].reshape(-1)
+        dense = renderer.stats()["dense_blocks"]
+        renderer.enable_stats(False)
+        return img, dense
+
     r = pkg.Renderer(0)
     buf = torch.zeros(w * h, dtype=torch.int32, device="cuda")
     try:
@@ -726,6 +737,35 @@ def test_dense_launch_is_left_out_only_while_nothing_changed(pkg, oracle, render
         assert dm > 0
         r.set_gaussians(monkey)                                       # another scene behind the same camera
         np.testing.assert_array_equal(frame(cam0), wantm)
+        # another tile grid behind the same camera, scene and options (round-2 advisor: prepare_tile_grid stamped nothing, so
+        # the first frame on the new grid ran without the dense launch): the launch is back for exactly one frame of the new
+        # grid, then -- that frame having reported -- left out again
+        settle(grid, cam0)
+        skips = r.stats()["dense_launch_skips"]
+        assert skips > 0
+        for tiles_n in (4, 16, 8):
+            r.frame_call(2 / tiles_n, 2 / tiles_n, cam0.view, cam0.position, pack)(buf.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert r.stats()["dense_launch_skips"] == skips, tiles_n          # first frame of this grid: not skipped
+            want_t, dense_t = fresh_tiles(grid, cam0, tiles_n)
+            np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), want_t)
+            for _ in range(3):
+                r.frame_call(2 / tiles_n, 2 / tiles_n, cam0.view, cam0.position, pack)(buf.data_ptr(), st)
+                torch.cuda.synchronize()
+            np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), want_t)
+            # ... settled again -- unless this grid HAS dense cells (8 tiles: longer tile lists, more careful thresholds below them,
+            # some cell lists beyond the dense threshold: the case the missing stamp got wrong)
+            assert (r.stats()["dense_launch_skips"] > skips) == (dense_t == 0), (tiles_n, dense_t)
+            skips = r.stats()["dense_launch_skips"]
+        # untiled (clear_tiles) -> device tiles
+        r.clear_tiles()
+        r.render_device(cam0.position, pack, buf.data_ptr(), 0, st)
+        torch.cuda.synchronize()
+        skips = r.stats()["dense_launch_skips"]
+        r.frame_call(2 / 16, 2 / 16, cam0.view, cam0.position, pack)(buf.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert r.stats()["dense_launch_skips"] == skips
+        np.testing.assert_array_equal(buf.cpu().numpy().view(np.uint32), want0)
         settle(grid, cam0)
         want_e, _ = fresh(grid, cam0, eps=0.0)
         r.set_options(pkg.EXP_VCL, pkg.ERF_AS, 0.0)                   # other options

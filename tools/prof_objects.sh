@@ -8,9 +8,9 @@ for cfg in "teapot 2048" "monkey 4096" "monkey 4096 0.12"; do
   echo "$tag done"
 done
 cd $R
-python3 - <<'PY'
+OUT=$OUT python3 - <<'PY'
 import csv, glob, collections, os
-OUT='/root/repo/gpurun_out/r02_obj'
+OUT=os.environ['OUT']
 PEAK=1024*2.4e9/2
 print("# rocprofv3 on the OBJ scenes (`tools/prof_object.py`, 5 frames each, MI355X, final kernels of round 2)\n")
 print("`--kernel-trace --stats` per-launch averages, and a separate `--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU` pass: VALU wave-instructions")
