@@ -263,8 +263,13 @@ int prep_frame(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
     int rc = rebuild_tables(c);
     if (rc) return rc;
     if (c->gA_valid && !memcmp(c->gA_origin, origin, 3 * sizeof(float))) return VRT_HIP_OK;
-    launch_prep_frame(tables(c), c->gA.p, origin, st);
-    HIPCHK(c, hipGetLastError());
+    if (c->defer) { // a frame of a batch: one prep launch for all frames (launch_frame_setup_batch)
+        c->defer->do_prep = 1; c->defer->prep_gA = c->gA.p;
+        memcpy(c->defer->prep_origin, origin, 3 * sizeof(float));
+    } else {
+        launch_prep_frame(tables(c), c->gA.p, origin, st);
+        HIPCHK(c, hipGetLastError());
+    }
     memcpy(c->gA_origin, origin, 3 * sizeof(float));
     c->cam_seq = c->frame_seq; // the camera moved
     c->gA_valid = true;
@@ -465,7 +470,13 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         const size_t rows = nt * (1 + cones_cells);
         if (key != c->cone_key || c->tile_cones.cap < 2 * rows) {
             HIPCHK(c, c->tile_cones.reserve(2 * rows));
-            launch_tile_cones(a, geo.tiles_h, cones_cells ? c->cells_x : 0u, cones_cells ? c->cells_y : 0u, c->tile_cones.p, st);
+            if (c->defer) { // a frame of a batch: one cone launch for all frames (its BinArgs are the frame's bin row)
+                c->defer->do_cones = 1; c->defer->cones_tiles = a.tiles_w * geo.tiles_h;
+                c->defer->cones_cx = cones_cells ? c->cells_x : 0u; c->defer->cones_cy = cones_cells ? c->cells_y : 0u;
+                c->defer->cones_out = c->tile_cones.p;
+            } else {
+                launch_tile_cones(a, geo.tiles_h, cones_cells ? c->cells_x : 0u, cones_cells ? c->cells_y : 0u, c->tile_cones.p, st);
+            }
             c->cone_key = key;
         }
         a.tile_cones = c->tile_cones.p; a.cones_cells = cones_cells;
@@ -1435,6 +1446,7 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
     for (int i = 0; i < n && !failed; ++i) {
         vrt_hip_ctx *c = ctxs[i];
         c->defer = &rows[i];
+        rows[i].do_prep = rows[i].do_cones = rows[i].do_order = 0;
         c->deferred = vrt_hip_ctx::Deferred{};
         touched = i + 1;
         int rc = vrt_hip_tile_gaussians_device(c, tw, th, views + 16 * (size_t)i, hip_stream);
@@ -1458,11 +1470,14 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
             if (c->c_counters.p && hipMemsetAsync(c->c_counters.p, 0, 16 * sizeof(uint32_t), st) != hipSuccess) (void)hipGetLastError();
             if (c->c_rq.p && hipMemsetAsync(c->c_rq.p, 0, 2 * RQ_N * RQ_STRIDE * sizeof(uint32_t), st) != hipSuccess) (void)hipGetLastError();
             c->lists_dirty = true; c->lists_fresh = false;
+            c->gA_valid = false; c->cone_key.clear(); // their deferred set-up launches were never made
         }
         return failed;
     }
+    for (int i = 0; i < n; ++i) rows[i].do_order = ctxs[i]->deferred.order ? 1 : 0;
     HIPCHK(c0, hipMemcpyAsync(d_rows, rows, (size_t)n * sizeof(FrameArgs), hipMemcpyHostToDevice, st));
     HIPCHK(c0, hipEventRecord(c0->batch_copied[slot], st));
+    launch_frame_setup_batch(d_rows, rows, (uint32_t)n, st); // per-origin tables and cone tables of the frames that need new ones
     const auto &d0 = c0->deferred;
     if (d0.lists) launch_build_tile_lists_batch(d_rows, (uint32_t)n, d0.from_list, d0.list_grid, st);
     // one-wave kernel: the persistent grid of ONE frame fills the GPU; n frames share it (at least one workgroup each --
@@ -1471,10 +1486,8 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
     const uint32_t rgrid = d0.render_grid ? std::min(d0.render_grid, std::max(1u, (d0.render_grid * oversub + (uint32_t)n - 1) / (uint32_t)n)) : 0u;
     launch_render_batch(d_rows, (uint32_t)n, rgrid, c0->exp_kind, c0->erf_kind, st);
     uint32_t dgrid = 0;
-    for (int i = 0; i < n; ++i) {
-        if (ctxs[i]->deferred.order) launch_order_dense(rows[i].C, st);
-        dgrid = std::max(dgrid, ctxs[i]->deferred.dense_grid);
-    }
+    for (int i = 0; i < n; ++i) dgrid = std::max(dgrid, ctxs[i]->deferred.dense_grid);
+    launch_order_dense_batch(d_rows, rows, (uint32_t)n, st);
     if (table_on(c0))
         launch_render_table_batch(d_rows, (uint32_t)n, std::min<uint32_t>(dgrid, (uint32_t)c0->num_cus), dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
     else

@@ -206,11 +206,19 @@ struct FrameArgs {
     BinArgs bin; FuseArgs fuse;                                   // list kernel
     SceneTables S; TileLists T; CellGrid C; RayGen R; RenderTarget O;   // one-wave kernel and dense kernel
     CellGrid C2;                                                  // table mode: the exact kernel's view of the queue of declined blocks
+    // the frame's small set-up kernels, batched too (a launch per frame and member costs more than the work: 512 launches of
+    // 14-20 us in a 128-frame orbit on four members, profiles/r03_group.md)
+    int do_prep;  float4 *prep_gA; float prep_origin[3];          // prep_frame_kernel: oc = mu - origin, |oc|^2
+    int do_cones; uint32_t cones_tiles, cones_cx, cones_cy; float4 *cones_out; // tile_cones_kernel for this frame's camera (bin = its rays and tile geometry)
+    int do_order;                                                 // order_dense_kernel
 };
 void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, uint32_t ntiles, hipStream_t st);
 void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
 void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int dw, int exp_kind, int erf_kind,
                                hipStream_t st);
+// the per-frame set-up kernels of a batch, one launch each: prep_frame (grid.y = frame), tile_cones, order_dense
+void launch_frame_setup_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st);
+void launch_order_dense_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st);
 void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, int exp_kind, int erf_kind,
                                hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,

@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_batch2_kernel(const F
 
 // Queue order of the dense kernel: cells by descending candidate count (a block costs ~ count^2), so that the
 // blocks still running when the queue empties are the cheapest ones.  Counting sort, one workgroup.
-__global__ __launch_bounds__(1024) void order_dense_kernel(CellGrid C)
+__device__ __forceinline__ void order_dense_body(const CellGrid &C)
 {
     __shared__ uint32_t s_hist[1024], s_scan[1024];
     const uint32_t n = *C.n_dense, tid = threadIdx.x;
@@ -1574,9 +1574,21 @@ __global__ __launch_bounds__(1024) void order_dense_kernel(CellGrid C)
     }
 }
 
+__global__ __launch_bounds__(1024) void order_dense_kernel(CellGrid C) { order_dense_body(C); }
+__global__ __launch_bounds__(1024) void order_dense_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.x];
+    if (a.do_order) order_dense_body(a.C);
+}
 void launch_order_dense(const CellGrid &c, hipStream_t st)
 {
     hipLaunchKernelGGL(order_dense_kernel, dim3(1), dim3(1024), 0, st, c);
+}
+void launch_order_dense_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st)
+{
+    bool any = false;
+    for (uint32_t f = 0; f < nframes; ++f) any = any || h_frames[f].do_order;
+    if (any) hipLaunchKernelGGL(order_dense_batch_kernel, dim3(nframes), dim3(1024), 0, st, d_frames);
 }
 
 #endif // !VRT_TU_LANES
@@ -1738,6 +1750,15 @@ __global__ void prep_frame_kernel(uint32_t n, const float4 *mu_sig, float4 *gA, 
     gA[i] = make_float4(cx, cy, cz, dot3_ref(cx, cy, cz, cx, cy, cz)); // vec4f_t::sqnorm order (types.h:69-72)
 }
 
+__global__ void prep_frame_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!a.do_prep || i >= a.S.n) return;
+    const float4 m = a.S.mu_sig[i];
+    const float cx = m.x - a.prep_origin[0], cy = m.y - a.prep_origin[1], cz = m.z - a.prep_origin[2];
+    a.prep_gA[i] = make_float4(cx, cy, cz, dot3_ref(cx, cy, cz, cx, cy, cz));
+}
 void launch_prep_frame(const SceneTables &s, float4 *gA_out, const float origin[3], hipStream_t st)
 {
     if (!s.n) return;
@@ -1806,6 +1827,31 @@ __global__ __launch_bounds__(256) void tile_cones_kernel(BinArgs P, uint32_t n_t
         out[2 * k] = make_float4(cn.cx, cn.cy, cn.cz, cn.cos_t);
         out[2 * k + 1] = make_float4(cn.sin_t, 0.f, 0.f, 0.f);
     }
+}
+__global__ __launch_bounds__(256) void tile_cones_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    if (!a.do_cones) return;
+    const BinArgs &P = a.bin;
+    const uint32_t per = 1 + a.cones_cx * a.cones_cy;
+    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= a.cones_tiles * per) return;
+    const uint32_t t = k / per, c = k % per;
+    const Cone cn = c ? cell_cone(P, t % P.tiles_w, t / P.tiles_w, c - 1, a.cones_cx, lane) : tile_cone(P, t % P.tiles_w, t / P.tiles_w, lane);
+    if (lane == 0) {
+        a.cones_out[2 * k] = make_float4(cn.cx, cn.cy, cn.cz, cn.cos_t);
+        a.cones_out[2 * k + 1] = make_float4(cn.sin_t, 0.f, 0.f, 0.f);
+    }
+}
+void launch_frame_setup_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st)
+{
+    uint32_t n_prep = 0, n_cones = 0;
+    for (uint32_t f = 0; f < nframes; ++f) {
+        if (h_frames[f].do_prep) n_prep = std::max(n_prep, h_frames[f].S.n);
+        if (h_frames[f].do_cones) n_cones = std::max(n_cones, h_frames[f].cones_tiles * (1 + h_frames[f].cones_cx * h_frames[f].cones_cy));
+    }
+    if (n_prep) hipLaunchKernelGGL(prep_frame_batch_kernel, dim3((n_prep + 255) / 256, nframes), dim3(256), 0, st, d_frames);
+    if (n_cones) hipLaunchKernelGGL(tile_cones_batch_kernel, dim3((n_cones + 3) / 4, nframes), dim3(256), 0, st, d_frames);
 }
 void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uint32_t cells_y, float4 *cones_out, hipStream_t st)
 {

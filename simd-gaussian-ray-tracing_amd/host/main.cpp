@@ -138,7 +138,8 @@ static int run_on_group(const cmd_args_t &cmd, const std::vector<vrt::gaussian_t
     devices.resize(cmd.gpus, devices.back());
     // whole frames dealt to the members (no exchange) when no frame has to be in one place; four members per GPU then,
     // like the four contexts of the single-GPU loop
-    const bool deal_frames = cmd.outfile == nullptr && cmd.nr_frames > 1;
+    // (VRT_CLI_GROUP_SHARD=1: tile-shard every frame even when none is written out -- to time the sharded path)
+    const bool deal_frames = cmd.outfile == nullptr && cmd.nr_frames > 1 && getenv("VRT_CLI_GROUP_SHARD") == nullptr;
     if (deal_frames) { const size_t n = devices.size(); for (size_t k = 0; k < 3 * n; ++k) devices.push_back(devices[k % n]); }
     vrt_hip_group *grp = nullptr;
     if (vrt_hip_group_create(devices.data(), (int)devices.size(), &grp) != VRT_HIP_OK) {
@@ -191,6 +192,17 @@ static int run_on_group(const cmd_args_t &cmd, const std::vector<vrt::gaussian_t
         const u64 per_batch = getenv("VRT_CLI_GROUP_BATCH") ? std::max(1, std::min(64, atoi(getenv("VRT_CLI_GROUP_BATCH")))) : 16;
         std::vector<std::vector<u32>> images(cmd.outfile ? per_batch : 0, std::vector<u32>(width * height));
         for (int i = 0; i < n; ++i) chk(vrt_hip_set_camera_view(vrt_hip_group_ctx(grp, i), (u32)width, (u32)height, cam.view_matrix.data()), "set_camera_view", vrt_hip_group_ctx(grp, i));
+        if (getenv("VRT_CLI_NO_WARMUP") == nullptr) {
+            // one untimed batch: the group creates its mirror contexts (per_batch - 1 per member) and their buffers on first use,
+            // which is set-up like the first launch above, not rendering time
+            const u64 nf = std::min<u64>(per_batch, cmd.nr_frames);
+            std::vector<f32> views(16 * nf), origins(3 * nf);
+            for (u64 f = 0; f < nf; ++f) {
+                memcpy(&views[16 * f], cam.view_matrix.data(), 16 * sizeof(f32));
+                for (int k = 0; k < 3; ++k) origins[3 * f + k] = cam.position[k];
+            }
+            chk(vrt_hip_group_frame_batch(grp, (int)nf, tw, th, views.data(), origins.data(), pack, nullptr, 1), "group_frame_batch", nullptr);
+        }
         for (u64 done = 0; done < cmd.nr_frames;) {
             const u64 nf = std::min<u64>(per_batch, cmd.nr_frames - done);
             std::vector<f32> views(16 * nf), origins(3 * nf);
