@@ -174,3 +174,52 @@ def test_cli_writes_the_reference_image(tmp_path):
     assert p.returncode == 0, p.stderr
     d = np.abs(np.array(Image.open(out2)).astype(np.int16) - thesis_png("cube"))
     assert d.max() <= 1 and (d == 0).mean() >= 0.99
+
+
+@pytest.mark.gpu
+def test_oracle_pin_light_subset_on_the_gpu_box(oracle):
+    """A light subset of the two oracle-vs-PNG pins above, marked `gpu` so that the driver's GPU record shows the pin of the
+    checker itself green next to the HIP path's (round-2 verdict): 120 + 150 sampled pixels, a few seconds of CPU."""
+    for name, obj, kw, n, seed in (("teapot", OBJ, dict(focal=FOCAL), 120, 7), ("cube", CUBE_OBJ, dict(focal=CUBE_FOCAL, initial_rot=CUBE_ROT), 150, 8)):
+        png = thesis_png(name)
+        g = oracle.read_obj(obj)
+        cam, _ = oracle.cli_camera(W, H, **kw)
+        tiles = oracle.tile_gaussians(2 / 16, 2 / 16, g, oracle.camera_view(cam))
+        pix = sample_pixels(png, n, seed=seed)
+        img, _ = oracle.render(W, H, oracle.camera_plane(cam), cam.position[:], g, tiles, pixels=pix)
+        d = np.abs(file_bytes(img[pix]) - png.reshape(-1, 4)[pix])
+        assert d.max() <= 1, (name, int(d.max()))
+        assert (d == 0).mean() >= 0.97, name
+
+
+@pytest.mark.gpu
+def test_notes_teapot_png_soft_check(pkg, renderer):
+    """`notes/teapot.png` (fixture tests/golden/notes/teapot.png): 512 x 512, alpha 255 everywhere -- an opaque-alpha render
+    of the teapot that the slides call a preliminary result.  tools/notes_png_fit.py (profiles/r03_notes_png_fit.md) finds
+    no CLI setting of THIS revision that reproduces it: its colours follow another albedo rule, and even the channel that
+    carries the plain sum of the emission terms (file channel 0 tracks this build's w radiance with correlation 0.999) is up
+    to 17 steps off on a quarter of the lit pixels -- an earlier revision of the code, so no golden vector for the scalar
+    modes.  What it does agree with is kept as a soft check of camera, OBJ loader and the opaque truncating pack: the lit
+    silhouette to a pixel and that channel within one step on >= 95 % of the image at -c -3.44."""
+    from PIL import Image
+    from sgrt_amd import scene
+    png = np.array(Image.open(os.path.join(GOLDEN, "notes", "teapot.png"))).astype(np.int64)
+    assert png.shape == (512, 512, 4) and (png[..., 3] == 255).all()
+    g = scene.read_obj(OBJ)
+    cam, _ = scene.cli_camera(512, 512, camera_offset=-3.44)
+    renderer.set_gaussians(g)
+    renderer.set_options(pkg.EXP_LIBM, pkg.ERF_LIBM, 1e-9)          # modes 1 / 5: expf, erff
+    try:
+        renderer.set_camera_view(512, 512, cam.view)
+        renderer.tile_gaussians(2 / 16, 2 / 16, cam.view)
+        img, rad = renderer.render(cam.position, pkg.PACK_TRUNC | pkg.ALPHA_OPAQUE)
+    finally:
+        renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
+    assert ((img >> 24) == 255).all()
+    w8 = np.floor(np.minimum(rad[..., 3].astype(np.float64), 1.0) * 255)
+    d = np.abs(w8 - png[..., 0])
+    assert (d <= 1).mean() >= 0.95 and d.mean() <= 0.3
+    ys, xs = np.nonzero(png[..., :3].sum(2) > 0)
+    yr, xr = np.nonzero(w8 > 0)
+    assert abs(int(xs.min()) - int(xr.min())) <= 2 and abs(int(xs.max()) - int(xr.max())) <= 2
+    assert abs(int(ys.min()) - int(yr.min())) <= 2 and abs(int(ys.max()) - int(yr.max())) <= 2
