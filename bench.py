@@ -489,6 +489,25 @@ def main():
             sweep[str(nf)] = (time.perf_counter() - t2) / n_serial * 1e3
         run(2 * nctx)   # every frame buffer holds the static frame again
         barrier()
+        # the same loop with the frame buffers declared "retained" (vrt_hip_frame_retained_device: each buffer is written by its
+        # context only and still holds its previous frame, like the reference's `image`): the list kernel then resets only the
+        # cells that went dark instead of writing 16 MB of background over background.  Reported next to the headline, which
+        # keeps the full clear of a caller's buffer.
+        rframes = [r_.frame_call(tw, th, view, origin, pack, retained=True) for r_ in ctxs]
+        for k in range(4 * nctx):
+            rframes[k % nctx](img_ptrs[k % nctx], sps[k % nctx])
+        barrier()
+        t2 = time.perf_counter()
+        for k in range(n_serial):
+            rframes[k % nctx](img_ptrs[k % nctx], sps[k % nctx])
+        barrier()
+        retained_ms = (time.perf_counter() - t2) / n_serial * 1e3
+        t2 = time.perf_counter()
+        for k in range(n_serial):
+            rframes[0](img_ptrs[0], sps[0])
+        barrier()
+        retained_serial_ms = (time.perf_counter() - t2) / n_serial * 1e3
+        sweep["retained_frame_buffers"] = {"frames_in_flight": nctx, "ms_per_step": retained_ms, "serial_ms_per_frame": retained_serial_ms}
     r.enable_kernel_timing(1)
     run(max(50, min(args.steps, 100)), 1, serial=True)
     barrier()
@@ -631,7 +650,7 @@ def main():
             # the same loop with one context: frame k+1 starts when frame k is done
             "serial": {"frames_in_flight": 1, "ms_per_step": serial_ms, "value": w * h / (serial_ms * 1e-3) / 1e6, "steps": n_serial},
             "moving_camera": moving,
-            "in_flight_sweep_ms_per_step": sweep,
+            "in_flight_sweep_ms_per_step": sweep,   # frames in flight -> ms per step; + the retained-buffer variant of the loop
             "valu": {**valu, "blocks": st["blocks"], "shaded_blocks": st["shaded_blocks"], "dense_blocks": st["dense_blocks"],
                      "mean_cell_list": st["tile_entries"] / sb, "mean_block_list": st["list_entries"] / sb,
                      "mean_ray_list": st["lane_entries"] / (sb * 64), "mean_block_longest_ray_list": st["lane_max_entries"] / sb,

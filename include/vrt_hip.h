@@ -169,6 +169,14 @@ int vrt_hip_render_device(vrt_hip_ctx *ctx, const float origin[3], int pack_flag
  * then render into d_image (raster order) or, when `shard` is non-zero, into this rank's compact shard buffer. */
 int vrt_hip_frame_device(vrt_hip_ctx *ctx, float tw, float th, const float view[16], const float origin[3],
                          int pack_flags, uint32_t *d_out, int shard, void *hip_stream);
+/* The same for a frame buffer that the CALLER promises still holds this context's previous frame, written by nothing else in
+ * between (the reference's `image` is such a buffer: allocated once, written every frame, main.cpp:245): only the cells
+ * that were lit in that frame and are empty now are reset to background, not all of them (16 MB of a 2048^2 frame's
+ * 18.7 MB of HBM traffic).  The same frame, bit for bit.  One history per context: another buffer, image size, tile grid
+ * or background value falls back to the full clear by itself; so does vrt_hip_frame (the library's own buffer gets this
+ * treatment without being asked). */
+int vrt_hip_frame_retained_device(vrt_hip_ctx *ctx, float tw, float th, const float view[16], const float origin[3],
+                                  int pack_flags, uint32_t *d_out, void *hip_stream);
 
 /* The same for callers without device memory of their own (the CLI): the frame goes to the context's own image
  * buffer on the context's stream.  image_out != NULL: copied out and waited for (a frame whose PNG is written);

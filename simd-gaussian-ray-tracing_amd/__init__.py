@@ -69,6 +69,7 @@ SYMBOLS = {
     "vrt_hip_render": (C.c_int, [_vp, _f32p, C.c_int, _u32p, _f32p]),
     "vrt_hip_render_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp, _vp]),
     "vrt_hip_frame_device": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, C.c_int, _vp]),
+    "vrt_hip_frame_retained_device": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, _vp]),
     "vrt_hip_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
     "vrt_hip_shard_pixels": (C.c_size_t, [_vp]),
     "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
@@ -271,13 +272,22 @@ class Renderer:
         self._chk(self._L.vrt_hip_render_device(self._h, _fp(_f3(origin)), pack, d_image, d_radiance or None,
                                                 stream or None), "render_device")
 
-    def frame_call(self, tw, th, view, origin, pack, shard=False):
+    def frame_call(self, tw, th, view, origin, pack, shard=False, retained=False):
         """Pre-marshalled per-frame call (tile_gaussians + render in ONE C call): returns f(d_out, stream).
-        The argument arrays are converted once, so an animation loop pays ~1 us of Python per frame."""
+        The argument arrays are converted once, so an animation loop pays ~1 us of Python per frame.
+        retained: vrt_hip_frame_retained_device -- the caller promises that d_out still holds this context's previous frame."""
         v = np.ascontiguousarray(view, np.float32).ravel().copy()
         o = _f3(origin).copy()
         fn, h, vp, op = self._L.vrt_hip_frame_device, self._h, _fp(v), _fp(o)
         tw, th, pack, shard = float(tw), float(th), int(pack), int(bool(shard))
+        if retained:
+            fnr = self._L.vrt_hip_frame_retained_device
+
+            def call_retained(d_out, stream=0, _keep=(v, o)):
+                rc = fnr(h, tw, th, vp, op, pack, d_out, stream or None)
+                if rc != 0:
+                    self._chk(rc, "frame_retained_device")
+            return call_retained
 
         def call(d_out, stream=0, _keep=(v, o)):
             rc = fn(h, tw, th, vp, op, pack, d_out, shard, stream or None)

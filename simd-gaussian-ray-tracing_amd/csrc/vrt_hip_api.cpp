@@ -166,6 +166,13 @@ struct vrt_hip_ctx {
     bool shard_dirty = true;
 
     // scratch + statistics
+    // d_image: the library's own frame buffer (vrt_hip_frame, vrt_hip_render).  Retained between vrt_hip_frame calls: own_stamp[cell]
+    // = own_seq of the last frame that lit the cell, valid while own_sig (image size, tile grid, background) stays and nothing else
+    // wrote the buffer (own_seq = 0: the next frame clears everything and starts a new history)
+    DevBuf<uint32_t> own_stamp;
+    uint32_t own_seq = 0;
+    uint64_t own_sig = 0;
+    bool retain_next = false; // set by vrt_hip_frame around its render_common call
     DevBuf<uint32_t> d_image;
     DevBuf<float4> d_rad;
     DevBuf<unsigned long long> d_stats, d_timeline; // d_timeline: VRT_HIP_TIMELINE=1 diagnostics
@@ -239,8 +246,12 @@ int rebuild_tables(vrt_hip_ctx *c)
     { int rc = quiesce(c); if (rc) return rc; } // frames in flight read the tables this rewrites
     HIPCHK(c, c->mu_sig.reserve(c->n)); HIPCHK(c, c->gA.reserve(c->n)); HIPCHK(c, c->gB.reserve(c->n));
     HIPCHK(c, c->gC.reserve(c->n)); HIPCHK(c, c->gD.reserve(c->n)); HIPCHK(c, c->iota.reserve(c->n));
+    // cull_eps bounds what ONE Gaussian dropped at the tile level could have contributed; a ray can lose all N of them, so
+    // for scenes beyond 4096 Gaussians the threshold shrinks with N: 3 * eps_eff * N stays at the 1.2e-5 of N = 4096 and the
+    // frame's worst case at 2.5e-5 whatever N is (the lower levels already scale with their list lengths)
+    const float eps_eff = c->cull_eps * std::min(1.f, 4096.f / (float)std::max(c->n, 1u));
     launch_build_static(c->n, c->soa[0].p, c->soa[1].p, c->soa[2].p, c->soa[3].p, c->soa[4].p, c->soa[5].p,
-                        c->has_alpha ? c->soa[6].p : nullptr, c->soa[7].p, c->soa[8].p, c->cull_eps,
+                        c->has_alpha ? c->soa[6].p : nullptr, c->soa[7].p, c->soa[8].p, eps_eff,
                         exp_floor_x(c->exp_kind), c->mu_sig.p, c->gB.p, c->gC.p, c->gD.p, c->stream);
     launch_iota(c->iota.p, c->n, c->stream);
     HIPCHK(c, hipGetLastError());
@@ -657,7 +668,9 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         c->lists_dirty = true; // the list kernel files the cell keys into THIS buffer
         o.sparse_cap = sparse_cap;
     }
+    if (c->retain_next && out_mode == OUT_RASTER && !use_shard && !c->defer) { o.stamp = c->own_stamp.p; o.stamp_seq = c->own_seq; }
     if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
+    if (o.stamp && !o.cleared) c->own_seq = 0; // the list kernel of this frame was not the fused one: nobody kept the stamps
     const TileLists t = work_lists(c);
     if (o.stats) {
         HIPCHK(c, hipMemsetAsync(c->d_stats.p, 0, 32 * sizeof(unsigned long long), st));
@@ -760,6 +773,35 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     return VRT_HIP_OK;
 }
 
+// Retained frame buffer (vrt_hip_frame's own buffer; vrt_hip_frame_retained_device for a caller's): `image` still holds this
+// context's previous frame at this geometry, so the list kernel clears only the cells that went dark (RenderTarget::stamp).
+// One history per context, for ONE buffer: another buffer, image size, tile grid or background starts a new one with a
+// full clear.  Sets retain_next for the render_common call that follows.
+int retained_begin(vrt_hip_ctx *c, uint32_t *image, float tw, float th, int pack_flags, hipStream_t st)
+{
+    const size_t npix = (size_t)c->w * c->h;
+    const uint32_t tiles_w = (uint32_t)std::ceil(2.f / tw), tiles_h = (uint32_t)std::ceil(2.f / th);
+    const uint32_t tile_w = (uint32_t)(uint64_t)(c->w * tw / 2.f), tile_h = (uint32_t)(uint64_t)(c->h * th / 2.f);
+    const uint32_t cx = (tile_w + CELL - 1) / CELL, cy = (tile_h + CELL - 1) / CELL;
+    const size_t cells = (size_t)tiles_w * tiles_h * cx * cy;
+    const uint64_t sig = ((uint64_t)c->w << 40) ^ ((uint64_t)c->h << 20) ^ ((uint64_t)tiles_w << 52) ^ ((uint64_t)tiles_h << 8) ^ ((uint64_t)tile_w << 30) ^
+                         tile_h ^ ((pack_flags & VRT_ALPHA_COMPUTED) ? 1ull << 63 : 0ull) ^ (uint64_t)(uintptr_t)image * 0x9E3779B97F4A7C15ull;
+    static const bool retain_on = [] { const char *e = getenv("VRT_HIP_RETAIN_FRAME"); return !e || atoi(e) != 0; }();
+    c->retain_next = retain_on && cells > 0 && cells < (1u << 28) && tiles_w <= 4096 && tiles_h <= 4096 && c->world == 1;
+    if (!c->retain_next) { c->own_seq = 0; return VRT_HIP_OK; }
+    if (sig != c->own_sig || c->own_seq == 0 || c->own_seq >= 0xFFFFFFF0u || c->own_stamp.cap < cells) {
+        if (c->own_stamp.cap < cells) { int rc = quiesce(c); if (rc) return rc; } // frames in flight write the old stamp buffer
+        HIPCHK(c, c->own_stamp.reserve(cells));
+        HIPCHK(c, hipMemsetAsync(c->own_stamp.p, 0, cells * sizeof(uint32_t), st));
+        if (sig != c->own_sig) HIPCHK(c, hipMemsetAsync(image, 0, npix * 4, st)); // pixels no tile of the NEW grid covers read 0
+        c->own_sig = sig;
+        c->own_seq = 1; // stamps of 0 = "never lit": with seq 1 every empty cell compares against 0 = seq - 1 and is cleared
+    } else {
+        ++c->own_seq;
+    }
+    return VRT_HIP_OK;
+}
+
 // Are the plane arrays an affine function of (row, column)?  Then rays are a pinhole bundle and the
 // corner rays of a tile bound its cone.  Anything else disables the tile-level cull (the per-block cull
 // works from the actual lane rays and stays exact for arbitrary arrays).
@@ -857,7 +899,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
     c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_overflow2.release(); c->c_counters.release(); c->c_rq.release(); c->c_slot.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
-    c->d_image.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
+    c->d_image.release(); c->own_stamp.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
     for (auto &r : c->retained) r.stamp.release();
     c->tile_cones.release();
@@ -1173,6 +1215,20 @@ int vrt_hip_frame_device(vrt_hip_ctx *c, float tw, float th, const float view[16
     return render_common(c, origin, pack_flags, d_out, nullptr, (hipStream_t)hip_stream, shard ? OUT_COMPACT : OUT_RASTER);
 }
 
+int vrt_hip_frame_retained_device(vrt_hip_ctx *c, float tw, float th, const float view[16], const float origin[3], int pack_flags,
+                                  uint32_t *d_out, void *hip_stream)
+{
+    if (!c || !origin || !d_out) return VRT_HIP_ERR_INVALID;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = retained_begin(c, d_out, tw, th, pack_flags, (hipStream_t)hip_stream))) return rc;
+    rc = vrt_hip_frame_device(c, tw, th, view, origin, pack_flags, d_out, 0, hip_stream);
+    c->retain_next = false;
+    if (rc) c->own_seq = 0;
+    return rc;
+}
+
 int vrt_hip_frame(vrt_hip_ctx *c, float tw, float th, const float view[16], const float origin[3], int pack_flags,
                   uint32_t *image_out, int wait)
 {
@@ -1184,8 +1240,14 @@ int vrt_hip_frame(vrt_hip_ctx *c, float tw, float th, const float view[16], cons
     if (c->d_image.cap < npix) { // first frame at this size: pixels no tile covers read 0
         HIPCHK(c, c->d_image.reserve(npix));
         HIPCHK(c, hipMemsetAsync(c->d_image.p, 0, npix * 4, c->stream));
+        c->own_seq = 0;
     }
-    if ((rc = vrt_hip_frame_device(c, tw, th, view, origin, pack_flags, c->d_image.p, 0, c->stream))) return rc;
+    // Retained frame buffer: d_image is written by nothing but this call and vrt_hip_render (which ends the history), so an
+    // empty cell that was empty in the previous frame already holds the background.
+    if ((rc = retained_begin(c, c->d_image.p, tw, th, pack_flags, c->stream))) return rc;
+    rc = vrt_hip_frame_device(c, tw, th, view, origin, pack_flags, c->d_image.p, 0, c->stream);
+    c->retain_next = false;
+    if (rc) { c->own_seq = 0; return rc; }
     if (image_out) HIPCHK(c, hipMemcpyAsync(image_out, c->d_image.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
     if (image_out || wait) HIPCHK(c, hipStreamSynchronize(c->stream));
     return VRT_HIP_OK;
@@ -1207,6 +1269,7 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npix = (size_t)c->w * c->h;
     HIPCHK(c, c->d_image.reserve(npix));
+    c->own_seq = 0; // the library's frame buffer gets another image: vrt_hip_frame's retained history of it ends
     if (radiance_out) HIPCHK(c, c->d_rad.reserve(npix));
     HIPCHK(c, hipMemsetAsync(c->d_image.p, 0, npix * 4, c->stream));
     if (radiance_out) HIPCHK(c, hipMemsetAsync(c->d_rad.p, 0, npix * 16, c->stream));

@@ -123,6 +123,12 @@ struct RenderTarget {
     uint32_t n_local_tiles;
     int compact;
     int cleared;              // empty cells were already cleared by the list kernel of this frame
+    // Retained frame buffer (vrt_hip_frame's own buffer): `image` still holds the previous frame of this context at this
+    // geometry.  stamp[tile * cells per tile + cell] = stamp_seq of the last frame the cell was lit in; the list kernel then
+    // clears only the empty cells that were lit in frame stamp_seq - 1 (16 MB of a 2048^2 frame's 18.7 MB of HBM traffic are
+    // background written over background otherwise).  nullptr: every empty cell is cleared.
+    uint32_t *stamp;
+    uint32_t stamp_seq;
     // Sparse shard (multi-GPU transport, vrt_hip_frame_sparse_device): only the 32x32-px cells some Gaussian reaches
     // are stored, cell-major: `image` points at the pixel region, pixel (cx, cy) of the cell in slot s at
     // image[s*1024 + cy*32 + cx]; slot = position in the active queue, or n_active + position in the dense queue.

@@ -2023,8 +2023,17 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     if (tl) tl[3] = wall_clock64();
     if (wave == 0) { // cpt <= 64: one flag per lane
         const uint32_t mine = lane < cpt ? s_flag[lane] : 2u;
-        const unsigned long long m_act = __ballot(mine == 1u), m_dense = __ballot(mine == 3u), m_empty = __ballot(mine == 0u);
+        const unsigned long long m_act = __ballot(mine == 1u), m_dense = __ballot(mine == 3u);
         const unsigned long long m_light = __ballot(mine == 5u);
+        // Retained frame buffer (RenderTarget::stamp): the buffer still holds this context's previous frame, so an empty cell
+        // needs its 4 KB of background only if it was lit then; a lit cell notes the frame it was lit in.
+        bool clear_me = mine == 0u;
+        if (F.O.stamp && lane < cpt) {
+            uint32_t *stamp = F.O.stamp + (size_t)t * cpt + lane;
+            if (mine == 0u) clear_me = *stamp == F.O.stamp_seq - 1u;
+            else *stamp = F.O.stamp_seq;
+        }
+        const unsigned long long m_empty = __ballot(clear_me);
         const uint32_t na = (uint32_t)__popcll(m_act), nd = (uint32_t)__popcll(m_dense), nl = (uint32_t)__popcll(m_light);
         // empty cells are not queued (count == 0 says it): most tiles of a sparse frame then add to no counter at all
         uint32_t base_a = 0, base_d = 0, base_l = 0;
@@ -2049,7 +2058,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
             const uint32_t pos = base_d + (uint32_t)__popcll(m_dense & below);
             C.dense[pos] = cell;
             if (C.slot) C.slot[cell] = pos | 0x80000000u;
-        } else if (mine == 0u) {
+        } else if (clear_me) {
             s_inact[(uint32_t)__popcll(m_empty & below)] = lane;
         }
     }

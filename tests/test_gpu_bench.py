@@ -51,4 +51,6 @@ def test_bench_line(tmp_path, steps, in_flight):
     assert d["ms_per_step"] * 0.8 < m["ms_per_step"] < 0.2 and d["ms_per_frame"] * 0.8 < m["serial_ms_per_frame"] < 0.3
     assert abs(m["value"] - 2048 * 2048 / (m["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * m["value"]
     sw = d["in_flight_sweep_ms_per_step"]
+    ret = sw.pop("retained_frame_buffers")
     assert sorted(sw) == [str(k) for k in range(1, in_flight + 1)] and all(0 < t < 0.2 for t in sw.values())
+    assert 0 < ret["ms_per_step"] < 0.2 and 0 < ret["serial_ms_per_frame"] < 0.2
