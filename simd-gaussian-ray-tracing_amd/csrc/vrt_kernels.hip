@@ -765,7 +765,7 @@ __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_batch_kernel(const 
 // 20 independent erf terms of an absorber one after the other through two registers to save VGPRs, so a wave that is
 // alone on its SIMD (the tail of the kernel) crawls; max-ilp interleaves them (145 VGPRs, three waves per SIMD, which is
 // what the persistent grid uses anyway).  The 16-wave dense kernel has the thread-level parallelism and keeps the default.
-#ifndef VRT_TU_LANES
+#if !defined(VRT_TU_LANES) && !defined(VRT_TU_TABLE)
 // ---------------------------------------------------------------------------------------------
 // Dense blocks (hundreds of candidates per 8x8 block: sigma of many pixels, rays of a block see the
 // same Gaussians).  One 16-wave workgroup per block: the block's candidates are culled cooperatively
@@ -1032,6 +1032,61 @@ __global__ __launch_bounds__(DW * 64, 4) void render_dense_batch_kernel(const Fr
     render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C, a.R, a.O);
 }
 
+template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
+__global__ __launch_bounds__(DW * 64, 4) void render_dense_batch2_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C2, a.R, a.O);
+}
+
+// Queue order of the dense kernel: cells by descending candidate count (a block costs ~ count^2), so that the
+// blocks still running when the queue empties are the cheapest ones.  Counting sort, one workgroup.
+__device__ __forceinline__ void order_dense_body(const CellGrid &C)
+{
+    __shared__ uint32_t s_hist[1024], s_scan[1024];
+    const uint32_t n = *C.n_dense, tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[1023u - (min(C.count[C.dense[i]], 4095u) >> 2)], 1u);
+    __syncthreads();
+    // exclusive prefix over the buckets (bucket 0 = longest lists)
+    uint32_t v = s_hist[tid];
+    s_scan[tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+    }
+    s_hist[tid] = s_scan[tid] - v;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t cell = C.dense[i];
+        C.dense_sorted[atomicAdd(&s_hist[1023u - (min(C.count[cell], 4095u) >> 2)], 1u)] = cell;
+    }
+}
+
+__global__ __launch_bounds__(1024) void order_dense_kernel(CellGrid C) { order_dense_body(C); }
+__global__ __launch_bounds__(1024) void order_dense_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.x];
+    if (a.do_order) order_dense_body(a.C);
+}
+void launch_order_dense(const CellGrid &c, hipStream_t st)
+{
+    hipLaunchKernelGGL(order_dense_kernel, dim3(1), dim3(1024), 0, st, c);
+}
+void launch_order_dense_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st)
+{
+    bool any = false;
+    for (uint32_t f = 0; f < nframes; ++f) any = any || h_frames[f].do_order;
+    if (any) hipLaunchKernelGGL(order_dense_batch_kernel, dim3(nframes), dim3(1024), 0, st, d_frames);
+}
+
+#endif // main translation unit
+
+#ifdef VRT_TU_TABLE
 // ---------------------------------------------------------------------------------------------
 // Table mode (default; vrt_hip_set_table_step(0) = the exact kernels only): dense blocks through a per-ray TABLE of the
 // transmittance exponent.  Along one ray  X(s) = sum_j A_j (E_j - Erf(s r_j - m_j))  is ONE function of s, and the radiance
@@ -1095,27 +1150,43 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
     float common = 0.f;
-    auto stage = [&](uint32_t chunk) {
-        const uint32_t j = chunk * TB_CH + wave, b = chunk & 1u;
-        float A = 0.f, m = 0.f, r = 0.f, E = 0.f;
-        if (j < cnt) { // wave-uniform
+    // Staging: wave w computes (A, m, E) of absorber w of a chunk for its 64 rays.  The absorber's two parameter rows come by
+    // wave-uniform loads issued one chunk AHEAD of their use (fetch(c + 2) before the node loop of chunk c): their latency --
+    // the longest single wait of a small block -- hides behind the erf terms.
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+    bool pv = false;
+    auto fetch = [&](uint32_t chunk) {
+        const uint32_t j = chunk * TB_CH + wave;
+        pv = j < cnt; // wave-uniform
+        if (pv) {
             const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
-            const float4 ca = uload(S.gA, idx), cb = uload(S.gB, idx);
-            const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
-            const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
-            A = cb.z * vexp<EXP>(-(d2 * cb.y));
-            m = mubar * cb.x;
+            pa = uload(S.gA, idx); pb = uload(S.gB, idx);
+        }
+    };
+    auto stage = [&](uint32_t chunk) { // from the rows fetched last
+        const uint32_t b = chunk & 1u;
+        float A = 0.f, m = 0.f, r = 0.f, E = 0.f;
+        if (pv) {
+            const float mubar = dot3_ref(pa.x, pa.y, pa.z, ray.nx, ray.ny, ray.nz);
+            const float d2 = sub_ref(pa.w, mul_ref(mubar, mubar));
+            A = pb.z * vexp<EXP>(-(d2 * pb.y));
+            m = mubar * pb.x;
             E = erf(-m);
-            r = cb.x;
+            r = pb.x;
         }
         lds.st.A[b][wave][lane] = A; lds.st.M[b][wave][lane] = m; lds.st.E[b][wave][lane] = E;
         if (lane == 0) lds.st_r[b][wave] = r;
     };
     const uint32_t chunks = (cnt + TB_CH - 1) / TB_CH;
+    fetch(0);
     stage(0);
+    if (chunks > 1) fetch(1);
     __syncthreads();
     for (uint32_t c = 0; c < chunks; ++c) {
-        if (c + 1 < chunks) stage(c + 1);
+        if (c + 1 < chunks) {
+            stage(c + 1);
+            if (c + 2 < chunks) fetch(c + 2);
+        }
         const uint32_t b = c & 1u, nj = min((uint32_t)TB_CH, cnt - c * TB_CH);
         // the next absorber's staged values are requested one iteration ahead (LDS latency behind the erf terms)
         float nA = lds.st.A[b][0][lane], nM = lds.st.M[b][0][lane], nE = lds.st.E[b][0][lane], nR = lds.st_r[b][0];
@@ -1124,27 +1195,32 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
             if (jj + 1 < nj) { nA = lds.st.A[b][jj + 1][lane]; nM = lds.st.M[b][jj + 1][lane]; nE = lds.st.E[b][jj + 1][lane]; nR = lds.st_r[b][jj + 1]; }
             const float hr = h * r;
             const float x0 = __builtin_fmaf(s_first, r, -m), x1 = __builtin_fmaf((float)(NT - 1), hr, x0);
-            // saturated over the wave's whole node range on all rays: Erf = -1 (absorber behind the nodes) or +1 (in front)
-            if (__all(x1 <= -SAT_M)) { common = __builtin_fmaf(A, E + 1.f, common); ++n_skip; continue; }
-            if (__all(x0 >= SAT_M)) { common = __builtin_fmaf(A, E - 1.f, common); ++n_skip; continue; }
-            if constexpr (ERF == VRT_ERF_AS) {
-                // one sign over the whole range on all rays (all but the absorbers whose kink lies inside it): Erf = +-(1 - R), so
-                // E - Erf = (E - 1) + R or (E + 1) - R -- ten instructions per term instead of twelve, no sign transfer
-                if (__all(x0 >= 0.f)) {
+            // Four wave-uniform questions about the argument range [x0, x1] of this wave's nodes on all rays, asked together (one
+            // after the other each would wait for its own vector compare to reach the scalar unit: a quarter of a small block's
+            // node loop): saturated -- Erf = -1 (the absorber lies behind the nodes) or +1 (in front): one fma; or of ONE sign (all
+            // but the absorbers whose kink lies inside the range): Erf = +-(1 - R), so E - Erf = (E - 1) + R or (E + 1) - R -- ten
+            // instructions per term instead of twelve, no sign transfer (v_bfi_b32: 4.3 issue cycles)
+            const bool sat_lo = __all(x1 <= -SAT_M), sat_hi = __all(x0 >= SAT_M);
+            const bool all_pos = ERF == VRT_ERF_AS && __all(x0 >= 0.f), all_neg = ERF == VRT_ERF_AS && __all(x1 <= 0.f);
+            if (sat_lo | sat_hi) {
+                common = __builtin_fmaf(A, sat_lo ? E + 1.f : E - 1.f, common);
+                ++n_skip;
+            } else if (all_pos) {
+                if constexpr (ERF == VRT_ERF_AS) {
                     const float Em1 = E - 1.f;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Em1 + erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
-                    continue;
                 }
-                if (__all(x1 <= 0.f)) {
+            } else if (all_neg) {
+                if constexpr (ERF == VRT_ERF_AS) {
                     const float Ep1 = E + 1.f;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Ep1 - erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
-                    continue;
                 }
-            }
+            } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+            }
         }
         __syncthreads(); // chunk c+1 is staged, and everyone is done with buffer b (chunk c+2 goes there)
     }
@@ -1157,7 +1233,7 @@ template <int EXP, int ERF>
 __device__ __forceinline__ void render_table_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R,
                                                   const RenderTarget &O)
 {
-    constexpr int DW = TB_DW, TC = TB_TC, EC = 4;
+    constexpr int DW = TB_DW, TC = TB_TC;
     __shared__ TableLds lds;
     __shared__ uint32_t s_wave_cnt[DW];
     __shared__ float s_rmax[DW];
@@ -1256,10 +1332,13 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
         bool ok = cnt <= (uint32_t)TC;
         float s_lo = INFINITY, s_hi = -INFINITY, r_max = 0.f;
         if (ok) {
+            // (rows by wave-uniform loads, the next iteration's requested before this one's arithmetic: here and in the passes below)
+            float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+            if (wave < cnt) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[wave]); na = uload(S.gA, i0_); nb = uload(S.gB, i0_); }
             for (uint32_t j = wave; j < cnt; j += DW) {
-                const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
-                const float4 a = uload(S.gA, idx);
-                const float r = uload(S.gB, idx).x;
+                const float4 a = na;
+                const float r = nb.x;
+                if (j + DW < cnt) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[j + DW]); na = uload(S.gA, in_); nb = uload(S.gB, in_); }
                 const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
                 s_hi = fmaxf(s_hi, mubar);
                 s_lo = fminf(s_lo, mubar - 2.8285f / r); // mubar - 4 sigma, sigma = 1/(sqrt2 r), rounded outwards
@@ -1317,9 +1396,11 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 for (uint32_t g = wave; g < G; g += DW) lds.hist[g][lane] = 0u;
                 __syncthreads();
                 float s_part = 0.f;
+                float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+                if (wave < cnt) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[wave]); na = uload(S.gA, i0_); nb = uload(S.gB, i0_); }
                 for (uint32_t j = wave; j < cnt; j += DW) {
-                    const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
-                    const float4 ca = uload(S.gA, idx), cb = uload(S.gB, idx);
+                    const float4 ca = na, cb = nb;
+                    if (j + DW < cnt) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[j + DW]); na = uload(S.gA, in_); nb = uload(S.gB, in_); }
                     const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
                     const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
                     const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
@@ -1429,16 +1510,21 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 // ---- emission: the emitters are dealt to the waves; X(s_ik) by 4-point Lagrange interpolation for the samples
                 //      of this segment; the error bound is accumulated beside the radiance ----
                 const float seg_lo = (float)(seg * SL), seg_hi = seg + 1 == nseg ? INFINITY : (float)((seg + 1) * SL);
-                for (uint32_t i0 = wave * EC; i0 < cnt; i0 += DW * EC) {
-#pragma unroll
-                    for (int e = 0; e < EC; ++e) {
-                        if (i0 + e >= cnt) break;
-                        const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[i0 + e]);
-                        const float4 a = uload(S.gA, idx);
+                // (emitter i of wave w: w, w + 16, ...; the five rows of the NEXT emitter are requested before this one's samples)
+                struct Rows { float4 a, ms, alb; float inv2s2, q; } nx = {};
+                auto fetch_rows = [&](uint32_t i) {
+                    const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[i]);
+                    nx.a = uload(S.gA, idx); nx.ms = uload(S.mu_sig, idx); nx.alb = uload(S.gC, idx);
+                    nx.inv2s2 = uload(S.gB, idx).y; nx.q = uload(S.gD, idx).y;
+                };
+                if (wave < cnt) fetch_rows(wave);
+                for (uint32_t i = wave; i < cnt; i += DW) {
+                    {
+                        const Rows cur = nx;
+                        if (i + DW < cnt) fetch_rows(i + DW);
+                        const float4 a = cur.a, ms = cur.ms, alb = cur.alb;
+                        const float inv2s2 = cur.inv2s2, q = cur.q;
                         const float e_mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
-                        const float4 ms = uload(S.mu_sig, idx);
-                        const float inv2s2 = uload(S.gB, idx).y;
-                        const float q = uload(S.gD, idx).y;
                         float inner = 0.f, inner_abs = 0.f, inner_s3 = 0.f;
 #pragma unroll
                         for (int k = 0; k < 5; ++k) {
@@ -1462,7 +1548,6 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                             inner_abs += fabsf(term);
                             inner_s3 = __builtin_fmaf(fabsf(term), (float)lds.s3[g][lane], inner_s3);
                         }
-                        const float4 alb = uload(S.gC, idx);
                         Lr = __builtin_fmaf(alb.x, inner, Lr);
                         Lg = __builtin_fmaf(alb.y, inner, Lg);
                         Lb = __builtin_fmaf(alb.z, inner, Lb);
@@ -1539,59 +1624,7 @@ __global__ __launch_bounds__(1024) void render_table_batch_kernel(const FrameArg
     const FrameArgs &a = frames[blockIdx.y];
     render_table_body<EXP, ERF>(a.S, a.T, a.C, a.R, a.O);
 }
-template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
-__global__ __launch_bounds__(DW * 64, 4) void render_dense_batch2_kernel(const FrameArgs *__restrict__ frames)
-{
-    const FrameArgs &a = frames[blockIdx.y];
-    render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C2, a.R, a.O);
-}
-
-// Queue order of the dense kernel: cells by descending candidate count (a block costs ~ count^2), so that the
-// blocks still running when the queue empties are the cheapest ones.  Counting sort, one workgroup.
-__device__ __forceinline__ void order_dense_body(const CellGrid &C)
-{
-    __shared__ uint32_t s_hist[1024], s_scan[1024];
-    const uint32_t n = *C.n_dense, tid = threadIdx.x;
-    s_hist[tid] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[1023u - (min(C.count[C.dense[i]], 4095u) >> 2)], 1u);
-    __syncthreads();
-    // exclusive prefix over the buckets (bucket 0 = longest lists)
-    uint32_t v = s_hist[tid];
-    s_scan[tid] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += add;
-        __syncthreads();
-    }
-    s_hist[tid] = s_scan[tid] - v;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024) {
-        const uint32_t cell = C.dense[i];
-        C.dense_sorted[atomicAdd(&s_hist[1023u - (min(C.count[cell], 4095u) >> 2)], 1u)] = cell;
-    }
-}
-
-__global__ __launch_bounds__(1024) void order_dense_kernel(CellGrid C) { order_dense_body(C); }
-__global__ __launch_bounds__(1024) void order_dense_batch_kernel(const FrameArgs *__restrict__ frames)
-{
-    const FrameArgs &a = frames[blockIdx.x];
-    if (a.do_order) order_dense_body(a.C);
-}
-void launch_order_dense(const CellGrid &c, hipStream_t st)
-{
-    hipLaunchKernelGGL(order_dense_kernel, dim3(1), dim3(1024), 0, st, c);
-}
-void launch_order_dense_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st)
-{
-    bool any = false;
-    for (uint32_t f = 0; f < nframes; ++f) any = any || h_frames[f].do_order;
-    if (any) hipLaunchKernelGGL(order_dense_batch_kernel, dim3(nframes), dim3(1024), 0, st, d_frames);
-}
-
-#endif // !VRT_TU_LANES
+#endif // VRT_TU_TABLE
 
 #ifdef VRT_TU_LANES
 template <int EXP, int ERF>
@@ -1636,6 +1669,37 @@ void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t g
 {
     VRT_DISPATCH_EXP_ERF(launch_render_batch_t, d_frames, nframes, grid, st);
 }
+#elif defined(VRT_TU_TABLE)
+// The table kernel's error bound is that of the Abramowitz-Stegun erf (its kink) or of a smoother one (libm); the Exp must
+// be an accurate one (Exp(a)Exp(b) = Exp(a + b)): four pairs are instantiated, the host keeps every other pair exact.
+#define VRT_DISPATCH_TABLE(FN, ...)                                                                \
+    switch (exp_kind * 8 + erf_kind) {                                                             \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM>(__VA_ARGS__); break;      \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS>(__VA_ARGS__); break;          \
+    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM>(__VA_ARGS__); break;        \
+    default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
+    }
+template <int EXP, int ERF>
+static void launch_render_table_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                                  const RenderTarget &o, uint32_t grid, hipStream_t st)
+{
+    if (grid == 0) return;
+    hipLaunchKernelGGL((render_table_kernel<EXP, ERF>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
+}
+void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                         const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+{
+    VRT_DISPATCH_TABLE(launch_render_table_t, s, t, c, r, o, grid, st);
+}
+template <int EXP, int ERF>
+static void launch_render_table_only_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, hipStream_t st)
+{
+    if (nframes && grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF>), dim3(grid, nframes), dim3(1024), 0, st, d_frames);
+}
+void launch_render_table_only_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+{
+    VRT_DISPATCH_TABLE(launch_render_table_only_batch_t, d_frames, nframes, grid, st);
+}
 #else
 
 template <int EXP, int ERF>
@@ -1669,33 +1733,11 @@ void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint
     VRT_DISPATCH_EXP_ERF(launch_render_dense_batch_t, d_frames, nframes, grid, dw, st);
 }
 
-// The table kernel's error bound is that of the Abramowitz-Stegun erf (its kink) or of a smoother one (libm); the Exp must
-// be an accurate one (Exp(a)Exp(b) = Exp(a + b)): four pairs are instantiated, the host keeps every other pair exact.
-#define VRT_DISPATCH_TABLE(FN, ...)                                                                \
-    switch (exp_kind * 8 + erf_kind) {                                                             \
-    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM>(__VA_ARGS__); break;      \
-    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS>(__VA_ARGS__); break;          \
-    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM>(__VA_ARGS__); break;        \
-    default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
-    }
+void launch_render_table_only_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st); // table TU
 template <int EXP, int ERF>
-static void launch_render_table_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
-                                  const RenderTarget &o, uint32_t grid, hipStream_t st)
+static void launch_render_table_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid2, int dw, hipStream_t st)
 {
-    if (grid == 0) return;
-    hipLaunchKernelGGL((render_table_kernel<EXP, ERF>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
-}
-void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
-                         const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
-{
-    VRT_DISPATCH_TABLE(launch_render_table_t, s, t, c, r, o, grid, st);
-}
-template <int EXP, int ERF>
-static void launch_render_table_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, hipStream_t st)
-{
-    if (!nframes) return;
-    if (grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF>), dim3(grid, nframes), dim3(1024), 0, st, d_frames);
-    if (!grid2) return;
+    if (!nframes || !grid2) return;
     const dim3 g(grid2, nframes);
     if (dw == 17) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 16, false>), g, dim3(1024), 0, st, d_frames);
     else if (dw == 16) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 16>), g, dim3(1024), 0, st, d_frames);
@@ -1706,7 +1748,8 @@ static void launch_render_table_batch_t(const FrameArgs *d_frames, uint32_t nfra
 void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, int exp_kind, int erf_kind,
                                hipStream_t st)
 {
-    VRT_DISPATCH_TABLE(launch_render_table_batch_t, d_frames, nframes, grid, grid2, dw, st);
+    launch_render_table_only_batch(d_frames, nframes, grid, exp_kind, erf_kind, st);
+    VRT_DISPATCH_EXP_ERF(launch_render_table_batch_t, d_frames, nframes, grid2, dw, st);
 }
 
 // ---------------------------------------------------------------------------------------------
