@@ -12,12 +12,13 @@ constexpr int CELL = 32;          // second-level cull region: 32x32 pixels = 4x
 constexpr int TCAP = 1024;        // a tile's candidates kept in LDS by the fused list kernel
 constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate cell kernel (one wave per cell)
 #ifndef VRT_PCAP
-#define VRT_PCAP 128
+#define VRT_PCAP 96
 #endif
 #ifndef VRT_PL
 #define VRT_PL 48
 #endif
-constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each)
+constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each; 96 since round 3 = the dense threshold: a block of
+                                  // this kernel never has more; the two kilobytes went to the pair-lane path's rows of per-ray values)
 #ifndef VRT_DCAP
 #define VRT_DCAP 1024
 #endif
@@ -77,6 +78,7 @@ struct CellGrid {
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
                                      // LDS slots: it hands them to the dense kernel, which runs after it
     uint32_t dense_threshold;        // a cell whose list is longer than this goes to the dense queue
+    int pair_lanes;                  // block kernel: blocks with short per-ray lists are shaded with (ray, emitter) pairs as lanes (shade_pairs)
     // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame (written by the one-wave kernel),
     // [2] = items (blocks) the dense kernel found in its queues, [3] = sequence number of the frame that wrote [2]
     // ([1] unused).  The host reads it frames later to SIZE the dense launch: a frame that is expected to have nothing

@@ -332,6 +332,115 @@ __device__ __forceinline__ void shade_lanes_balanced(const float4 *s_A, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// (ray, emitter) PAIRS as lanes (round 3).  shade_chunk above gives every lane its ray and runs up to six of the ray's
+// emitters side by side: all lanes loop to the block's longest list, so a ray with 3 entries beside one with 6 idles through
+// half of the emitter slots AND half of the absorber iterations (64 % useful lanes on `-g 64 -w 2048`).  Here the emitters of all
+// 64 rays are packed densely: pair p = (ray, e-th entry of its list), lane = pair, NPASS = ceil(pairs / 64) passes held side
+// by side in registers.  Per absorber slot j every lane first computes, AS A RAY, its j-th absorber's (A, m, E, r) -- once per
+// (ray, absorber), as before -- and puts them into a 1-KB LDS row, from which each pass fetches the values of its pair's ray with
+// one 16-byte read (by ds_bpermute, four per pass and slot, the LDS instructions ate the gain: VALU -11 %, wave cycles +2 %); then
+// the five terms of the pair.  Emitter slots are no longer padded; absorber slots still are (a pair whose ray has no j-th absorber
+// adds A = 0).  The inner sums go through LDS back to the ray's lane, which adds them in list order.
+// LDS: the tail of s_lane (lists are at most PAIR_PL = 8 long on this path): pair -> ray map, the rays' first pair, the inner sums.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t PAIR_PL = 8, PAIR_NPASS_MAX = 6;
+static_assert(PL * 64 >= PAIR_PL * 64 + 512 + 256 + PAIR_NPASS_MAX * 64 * 4, "s_lane holds the pair path's scratch behind the lists");
+template <int EXP, int ERF, int NPASS>
+__device__ __forceinline__ void shade_pairs(const float4 *s_A, const float4 *s_B, const float4 *s_M, const float4 *s_C, const float *s_q,
+                                            float4 *s_pre /* [2][64] */, uint8_t *s_lane, uint32_t nl, uint32_t nmax, uint32_t first_pair, uint32_t n_pairs, uint32_t lane,
+                                            const LaneRay &ray, float &Lr, float &Lg, float &Lb, float &La)
+{
+    const ErfEval<ERF> erf;
+    uint8_t *s_map = s_lane + PAIR_PL * 64;                                   // [<= 384] ray of pair p
+    uint32_t *s_first = reinterpret_cast<uint32_t *>(s_lane + PAIR_PL * 64 + 512);  // [64] first pair of ray l
+    float *s_inner = reinterpret_cast<float *>(s_lane + PAIR_PL * 64 + 512 + 256);  // [<= 384] inner sum of pair p
+    for (uint32_t e = 0; e < nmax; ++e)
+        if (e < nl) s_map[first_pair + e] = (uint8_t)lane;
+    s_first[lane] = first_pair;
+    __syncthreads();
+    // the pairs of this lane, one per pass
+    uint32_t p_ray[NPASS], p_li[NPASS];
+    float e_mubar[NPASS], e_sigma[NPASS], acc[NPASS][5];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const uint32_t p = (uint32_t)q * 64u + lane;
+        const bool vp = p < n_pairs;
+        p_ray[q] = vp ? s_map[p] : 0u;
+        const uint32_t e = vp ? p - s_first[p_ray[q]] : 0u;
+        p_li[q] = vp ? s_lane[e * 64 + p_ray[q]] : 0u;
+        const float nx = __shfl(ray.nx, (int)p_ray[q], 64), ny = __shfl(ray.ny, (int)p_ray[q], 64), nz = __shfl(ray.nz, (int)p_ray[q], 64);
+        const float4 a = s_A[p_li[q]];
+        e_mubar[q] = dot3_ref(a.x, a.y, a.z, nx, ny, nz);
+        e_sigma[q] = s_M[p_li[q]].w;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[q][k] = 0.f;
+    }
+    // absorber slots.  The rays' values of slot j + 1 are computed while the passes work on slot j (two rows of LDS; one
+    // wavefront: its LDS instructions execute in order, so a row written before it is read needs no barrier, only the
+    // compiler kept from reordering the two)
+    auto ray_values = [&](uint32_t j) {
+        const bool vj = j < nl;
+        const uint32_t lj = vj ? s_lane[j * 64 + lane] : 0u;
+        const float4 ca = s_A[lj], cb = s_B[lj];
+        const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+        const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+        const float A = vj ? cb.z * vexp<EXP>(-(d2 * cb.y)) : 0.f;
+        const float m = mubar * cb.x;
+        return make_float4(A, m, erf(-m), cb.x);
+    };
+    s_pre[lane] = ray_values(0);
+    for (uint32_t j = 0; j < nmax; ++j) {
+        __builtin_amdgcn_wave_barrier();
+        const float4 *row = s_pre + (j & 1u) * 64u;
+        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j + 1 < nmax) nxt = ray_values(j + 1);
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const float4 v = row[p_ray[q]];
+            const float base = __builtin_fmaf(e_mubar[q], v.w, -v.y);
+            const float step = e_sigma[q] * v.w;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[q][k] = __builtin_fmaf(v.x, v.z - erf(__builtin_fmaf((float)(k - 4), step, base)), acc[q][k]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (j + 1 < nmax) s_pre[((j + 1) & 1u) * 64u + lane] = nxt;
+    }
+    // emission (see shade_list), per pair
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const uint32_t p = (uint32_t)q * 64u + lane;
+        const float nx = __shfl(ray.nx, (int)p_ray[q], 64), ny = __shfl(ray.ny, (int)p_ray[q], 64), nz = __shfl(ray.nz, (int)p_ray[q], 64);
+        const float4 ms = s_M[p_li[q]];
+        const float inv2s2 = s_B[p_li[q]].y;
+        const float qq = s_q[p_li[q]];
+        float inner = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[q]);
+            const float px = sub_ref(madd_ref(nx, sk, ray.ox), ms.x);
+            const float py = sub_ref(madd_ref(ny, sk, ray.oy), ms.y);
+            const float pz = sub_ref(madd_ref(nz, sk, ray.oz), ms.z);
+            const float dd = dot3_ref(px, py, pz, px, py, pz);
+            inner += emission_term<EXP>(qq, dd * inv2s2, acc[q][k]);
+        }
+        if (p < n_pairs) s_inner[p] = inner;
+    }
+    __syncthreads();
+    // back on the ray's lane: its emitters in list order
+    Lr = Lg = Lb = La = 0.f;
+    for (uint32_t e = 0; e < nmax; ++e) {
+        if (e < nl) {
+            const float inner = s_inner[first_pair + e];
+            const float4 alb = s_C[s_lane[e * 64 + lane]];
+            Lr = __builtin_fmaf(alb.x, inner, Lr);
+            Lg = __builtin_fmaf(alb.y, inner, Lg);
+            Lb = __builtin_fmaf(alb.z, inner, Lb);
+            La = __builtin_fmaf(alb.w, inner, La);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Rays and cones
 // ---------------------------------------------------------------------------------------------
 // (column, row) of raster index pix; 32-bit division whenever the index fits (a 64-bit divide is a ~150-instruction
@@ -534,6 +643,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     __shared__ float4 s_A[PCAP], s_B[PCAP], s_M[PCAP], s_C[PCAP];
     __shared__ float s_q[PCAP];
     __shared__ uint8_t s_lane[PL * 64];
+    __shared__ float4 s_pre[NW == 1 ? 128 : 1]; // pair lanes: the rays' (A, m, E, r) of the current and the next absorber slot
     __shared__ float4 s_L[NW > 1 ? 64 : 1];
     __shared__ uint32_t s_cnt[2], s_item;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wave = blockIdx.x, G = gridDim.x;
@@ -719,7 +829,29 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
         float Lr, Lg, Lb, La;
         if constexpr (NW == 1) {
-            if constexpr (VRT_RENDER_ECMAX > 4) shade_lanes_balanced<EXP, ERF, VRT_RENDER_ECMAX>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+            // short lists (sparse scenes): (ray, emitter) pairs as lanes; a function of the block alone (its list lengths)
+            uint32_t incl = nl;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= (uint32_t)off) incl += up;
+            }
+            const uint32_t n_pairs = (uint32_t)__shfl((int)incl, 63, 64), npass = (n_pairs + 63u) / 64u;
+            // instruction counts of the two layouts for this block (per lane; absorber set-up 30-35, five terms 60-66, an emission 160):
+            // ray per lane -- balanced chunks of at most 6 emitters, every chunk walks all nmax absorber slots; pairs -- npass passes
+            const uint32_t chunks = (nmax + VRT_RENDER_ECMAX - 1) / VRT_RENDER_ECMAX;
+            const uint32_t cost_rays = nmax * (30u * chunks + 60u * nmax) + 160u * nmax;
+            const uint32_t cost_pairs = nmax * (35u + 66u * npass) + 160u * npass + 150u;
+            if (C.pair_lanes && nmax <= PAIR_PL && npass >= 1u && npass <= PAIR_NPASS_MAX && (C.pair_lanes > 1 || cost_pairs * 20u < cost_rays * 19u)) {
+                switch (npass) {
+                case 1: shade_pairs<EXP, ERF, 1>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
+                case 2: shade_pairs<EXP, ERF, 2>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
+                case 3: shade_pairs<EXP, ERF, 3>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
+                case 4: shade_pairs<EXP, ERF, 4>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
+                case 5: shade_pairs<EXP, ERF, 5>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
+                default: shade_pairs<EXP, ERF, 6>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
+                }
+            } else if constexpr (VRT_RENDER_ECMAX > 4) shade_lanes_balanced<EXP, ERF, VRT_RENDER_ECMAX>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
             else shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
             write_block(Lr, Lg, Lb, La, valid, out);
         } else {
