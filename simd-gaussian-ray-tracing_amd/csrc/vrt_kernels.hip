@@ -643,7 +643,9 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     __shared__ float4 s_A[PCAP], s_B[PCAP], s_M[PCAP], s_C[PCAP];
     __shared__ float s_q[PCAP];
     __shared__ uint8_t s_lane[PL * 64];
+#ifdef VRT_PAIR_LANES
     __shared__ float4 s_pre[NW == 1 ? 128 : 1]; // pair lanes: the rays' (A, m, E, r) of the current and the next absorber slot
+#endif
     __shared__ float4 s_L[NW > 1 ? 64 : 1];
     __shared__ uint32_t s_cnt[2], s_item;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wave = blockIdx.x, G = gridDim.x;
@@ -829,6 +831,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
         float Lr, Lg, Lb, La;
         if constexpr (NW == 1) {
+#ifdef VRT_PAIR_LANES // experiment (profiles/r03_experiments.md): make LANES='-DVRT_RENDER_ECMAX=6 -DVRT_RENDER_WPE=3 -DVRT_PAIR_LANES', VRT_HIP_PAIR_LANES=1|2
             // short lists (sparse scenes): (ray, emitter) pairs as lanes; a function of the block alone (its list lengths)
             uint32_t incl = nl;
 #pragma unroll
@@ -851,7 +854,9 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
                 case 5: shade_pairs<EXP, ERF, 5>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
                 default: shade_pairs<EXP, ERF, 6>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
                 }
-            } else if constexpr (VRT_RENDER_ECMAX > 4) shade_lanes_balanced<EXP, ERF, VRT_RENDER_ECMAX>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+            } else
+#endif
+            if constexpr (VRT_RENDER_ECMAX > 4) shade_lanes_balanced<EXP, ERF, VRT_RENDER_ECMAX>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
             else shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
             write_block(Lr, Lg, Lb, La, valid, out);
         } else {

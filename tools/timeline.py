@@ -1,0 +1,18 @@
+"""VRT_HIP_TIMELINE of one `-g 64 -w 2048` frame (the library prints the per-phase stamps of the list kernel and the block kernel on stderr).
+    VRT_HIP_TIMELINE=1 python3 tools/timeline.py [grid] [width] [pair_lanes]  2> profiles/rNN_timeline.txt"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+os.environ.setdefault("VRT_HIP_TIMELINE", "1")
+grid = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+if len(sys.argv) > 3: os.environ["VRT_HIP_PAIR_LANES"] = sys.argv[3]
+from conftest import load_pkg
+pkg = load_pkg()
+from sgrt_amd import scene
+cam, _ = scene.cli_camera(w, w)
+r = pkg.Renderer(0)
+r.set_gaussians(scene.grid_scene(grid)); r.set_camera_view(w, w, cam.view); r.tile_gaussians(2 / 16, 2 / 16, cam.view)
+for _ in range(3): r.render(cam.position)
+sys.stderr.write(f"# -g {grid} -w {w}: the frame below (third of three; pair lanes {os.environ.get('VRT_HIP_PAIR_LANES', '0')})\n"); sys.stderr.flush()
+r.render(cam.position)
+r.close()

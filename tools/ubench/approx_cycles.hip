@@ -18,6 +18,7 @@ __global__ void k(float *out, unsigned long long *stamps, float lo, float hi, in
     const float span = hi - lo;
     for (int i = 0; i < 8; ++i) { x[i] = lo + span * (float)((threadIdx.x * 8 + i) % 509) / 509.f; acc[i] = 0.f; }
     const float step = span * 0.0137f;
+    const unsigned long long r0 = wall_clock64(); // 100 MHz: calibrates the s_memtime tick
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -28,6 +29,8 @@ __global__ void k(float *out, unsigned long long *stamps, float lo, float hi, in
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[2 * gridDim.x] = t1 - t0; stamps[2 * gridDim.x + 1] = r1 - r0; }
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -45,13 +48,14 @@ static void run(const char *name, int cus, float *out, unsigned long long *stamp
     (void)hipMemcpy(stamps, init.data(), init.size() * 8, hipMemcpyHostToDevice);
     hipLaunchKernelGGL((k<KIND, IS_ERF>), dim3(cus), dim3(threads), 0, 0, out, stamps, lo, hi, iters);
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(2 * cus);
+    std::vector<unsigned long long> h(2 * cus + 2);
     (void)hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
     std::vector<double> cyc(cus);
     for (int i = 0; i < cus; ++i) cyc[i] = (double)(h[2 * i + 1] - h[2 * i]) / ((double)iters * 8 * wps); // per wave-evaluation per SIMD
     std::nth_element(cyc.begin(), cyc.begin() + cus / 2, cyc.end());
     const double c = cyc[cus / 2] - 2 * 3.1; // the loop's own add + wrap (two full-rate instructions and a compare/select ~ 3 more) is left in: see note
-    printf("| %-28s | %6.1f | %6.3f |\n", name, cyc[cus / 2], cyc[cus / 2] / 64.0);
+    const double mhz = (double)h[2 * cus] / ((double)h[2 * cus + 1] * 0.01); // s_memtime ticks per microsecond
+    printf("| %-28s | %6.1f | %6.3f | %.0f MHz |\n", name, cyc[cus / 2], cyc[cus / 2] / 64.0, mhz);
     (void)c;
 }
 
@@ -60,8 +64,8 @@ int main()
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     float *out; unsigned long long *stamps;
-    (void)hipMalloc(&out, sizeof(float) * 1024 * cus); (void)hipMalloc(&stamps, 16 * cus);
-    printf("| variant (csrc/vrt_device_math.h) | cycles per wave64 evaluation per SIMD (4 waves per SIMD; includes the loop's 4 bookkeeping instructions, ~13 cycles) | cycles per value |\n|---|---|---|\n");
+    (void)hipMalloc(&out, sizeof(float) * 1024 * cus); (void)hipMalloc(&stamps, 16 * cus + 16);
+    printf("| variant (csrc/vrt_device_math.h) | cycles per wave64 evaluation per SIMD (4 waves per SIMD; includes the loop's 4 bookkeeping instructions, ~13 cycles) | cycles per value | s_memtime tick rate (against the 100-MHz s_memrealtime) |\n|---|---|---|---|\n");
     run<VRT_ERF_LIBM, true>("erf: erff (libm)", cus, out, stamps);
     run<VRT_ERF_AS, true>("erf: Abramowitz-Stegun", cus, out, stamps);
     run<VRT_ERF_SPLINE, true>("erf: spline", cus, out, stamps);
