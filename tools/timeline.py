@@ -12,7 +12,7 @@ from sgrt_amd import scene
 cam, _ = scene.cli_camera(w, w)
 r = pkg.Renderer(0)
 r.set_gaussians(scene.grid_scene(grid)); r.set_camera_view(w, w, cam.view); r.tile_gaussians(2 / 16, 2 / 16, cam.view)
-for _ in range(3): r.render(cam.position)
+for _ in range(3): r.render(cam.position, want_radiance=False)  # image only, like the frame path (16-byte clears)
 sys.stderr.write(f"# -g {grid} -w {w}: the frame below (third of three; pair lanes {os.environ.get('VRT_HIP_PAIR_LANES', '0')})\n"); sys.stderr.flush()
-r.render(cam.position)
+r.render(cam.position, want_radiance=False)
 r.close()
