@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--tiles", type=int, default=16)
     ap.add_argument("--cull-eps", type=float, default=1e-9)
+    ap.add_argument("--cull-prune", type=float, default=6.0, help="budget factor of the block kernel's ray-level prune (library default 6; 0 = off)")
     ap.add_argument("--gather-frames", type=int, default=32, help="N > 1: frames per RCCL gather (one collective per batch)")
     ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
     ap.add_argument("--setup-ms", type=float, default=50.0, help="untimed set-up frames before the warm-up steps, in milliseconds of wall time")
@@ -271,6 +272,7 @@ def main():
         else:
             r_.set_camera_view(w, h, view)   # in-kernel rays = the reference's plane points, bit for bit (camera.cpp:60-69)
         r_.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
+        r_.set_cull_prune(args.cull_prune)
         r_.set_shard(*((0, 1) if solo else (rank, world)))
         return r_
 
@@ -617,7 +619,7 @@ def main():
             # several frames in flight is a throughput figure
             "ms_per_frame": serial_ms if solo else ms_per_step,
             "higher_is_better": True, "scaling": "weak" if (solo and world > 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"-g {args.grid} -w {w} (tiles {args.tiles}, mode-8 packing, cull_eps {args.cull_eps:g}, "
+            "config": {"workload": f"-g {args.grid} -w {w} (tiles {args.tiles}, mode-8 packing, cull_eps {args.cull_eps:g}, ray-level prune {args.cull_prune:g}, "
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
                        "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
                        "parallelism": (f"whole frames on each of {world} ranks, no collective" if (solo and world > 1) else

@@ -305,10 +305,16 @@ int vrt_hip_eval_exp(vrt_hip_ctx *ctx, int exp_kind, const float *x, size_t n, f
  * the exact kernels only, which reproduce the reference's per-term sums).  Every ray's worst-case radiance change --
  * sum over its samples of |term| * (0.0212 u^2 * K + 0.36 u^4 * S_all), see render_table_body in csrc/vrt_kernels.hip --
  * must stay below the budget (default 2.5e-5), or the block is redone at 0.6 of the spacing and then shaded exactly; so
- * are blocks with more than 512 survivors or a depth range the nodes cannot cover at 2.5 x the requested spacing.
+ * are blocks with more than 2048 survivors.
  * Applies to the Exp / Erf pairs {vcl_exp, expf} x {A&S erf, erff}; other pairs are always exact. */
 int vrt_hip_set_table_step(vrt_hip_ctx *ctx, float step);
 int vrt_hip_set_table_budget(vrt_hip_ctx *ctx, float budget);
+
+/* Budgeted ray-level cull of the one-wave ("block") kernel.  `cull_eps` (vrt_hip_set_options; replaces nothing in the reference,
+ * which sums every Gaussian of a tile: rt.h:205-223) bounds what dropped Gaussians can change by worst-case counting; a ray's own
+ * list is additionally cut by the SUM of what it drops: the smallest entries go while sum sigma*mag*exp(-x) <= kappa * 1365 * cull_eps
+ * (default kappa 6: the ray's radiance changes by at most 3 * that = 2.46e-5; 0 = off; cull_eps = 0 switches every cull off). */
+int vrt_hip_set_cull_prune(vrt_hip_ctx *ctx, float kappa);
 
 /* -------- statistics of the last render ----------------------------------------------------- */
 typedef struct {

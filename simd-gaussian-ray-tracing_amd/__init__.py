@@ -75,6 +75,7 @@ SYMBOLS = {
     "vrt_hip_render_shard_device": (C.c_int, [_vp, _f32p, C.c_int, _vp, _vp]),
     "vrt_hip_set_table_step": (C.c_int, [_vp, C.c_float]),
     "vrt_hip_set_table_budget": (C.c_int, [_vp, C.c_float]),
+    "vrt_hip_set_cull_prune": (C.c_int, [_vp, C.c_float]),
     "vrt_hip_set_camera_view": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p]),
     "vrt_hip_frame": (C.c_int, [_vp, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _vp, C.c_int]),
     "vrt_hip_sync": (C.c_int, [_vp]),
@@ -450,6 +451,10 @@ class Renderer:
         """Table mode for dense blocks (default 0.05; 0 = exact kernels only): see vrt_hip_set_table_step in include/vrt_hip.h."""
         self._chk(self._L.vrt_hip_set_table_step(self._h, float(step)), "set_table_step")
         self.table_step = float(step)
+
+    def set_cull_prune(self, kappa):
+        """Budget factor of the block kernel's ray-level prune (default 6; 0 = off): see vrt_hip_set_cull_prune in include/vrt_hip.h."""
+        self._chk(self._L.vrt_hip_set_cull_prune(self._h, float(kappa)), "set_cull_prune")
 
     def set_table_budget(self, budget):
         """Largest worst-case change of a ray's radiance the table kernel may cause (default 2.5e-5)."""

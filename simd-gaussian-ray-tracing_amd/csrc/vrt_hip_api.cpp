@@ -112,6 +112,8 @@ struct vrt_hip_ctx {
                                  // lanes where an instruction-count model says they are cheaper; 2: wherever they fit.  Measured: -10 % VALU
                                  // instructions, -1 % time (profiles/r03_experiments.md): off
     bool skip_idle_dense = true; // VRT_HIP_DENSE_SKIP=0: the dense kernel is launched behind every block kernel
+    float cull_prune = 6.f;      // vrt_hip_set_cull_prune(): a block-kernel ray may drop the smallest entries of its list while their sum stays below
+                                 // cull_prune * cull_ref_n * cull_eps (prune_list; 0 = off).  6: 3 * 6 * 1365 * 1e-9 = 2.46e-5 -- DESIGN.md section 4
     float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
@@ -415,6 +417,8 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
     g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.table_room = c->table_room; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
     g.pair_lanes = c->pair_lanes;
+    // prune_list sums sigma*mag*exp(-x) in units of the TILE level's eps (cull_x = ln(sigma*mag / eps_eff), rebuild_tables)
+    g.prune_budget = (c->cull_eps > 0.f) ? c->cull_prune * (c->cull_ref_n > 0.f ? c->cull_ref_n : 4096.f / 3.f) * std::max(1.f, (float)c->n / 4096.f) : 0.f;
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
     g.feedback = c->d_fb;
     g.dense_is_sorted = 1;
@@ -863,6 +867,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
     }
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
+    if (const char *e = getenv("VRT_HIP_CULL_PRUNE")) c->cull_prune = fmaxf(0.f, (float)atof(e));
     if (const char *e = getenv("VRT_HIP_TABLE_STEP")) { const float v = (float)atof(e); if (v >= 0.f && v <= 1.f) c->table_hx = v; }
     if (const char *e = getenv("VRT_HIP_TABLE_ROOM")) { const float v = (float)atof(e); if (v > 0.f && v <= 10.f) c->table_room = v; }
     if (const char *e = getenv("VRT_HIP_TABLE_ADAPT")) { const float v = (float)atof(e); if (v >= 1.f && v <= 3.f) c->table_adapt = v; }
@@ -991,7 +996,7 @@ int vrt_hip_copy_state(vrt_hip_ctx *dst, const vrt_hip_ctx *src)
         if (src->n && src->soa[i].p) HIPCHK(dst, hipMemcpy(dst->soa[i].p, src->soa[i].p, (size_t)src->n * sizeof(float), hipMemcpyDeviceToDevice));
     }
     dst->has_alpha = src->has_alpha; dst->n = src->n;
-    dst->exp_kind = src->exp_kind; dst->erf_kind = src->erf_kind; dst->cull_eps = src->cull_eps;
+    dst->exp_kind = src->exp_kind; dst->erf_kind = src->erf_kind; dst->cull_eps = src->cull_eps; dst->cull_prune = src->cull_prune;
     dst->table_hx = src->table_hx; dst->table_budget = src->table_budget; dst->table_adapt = src->table_adapt; dst->table_room = src->table_room;
     dst->rank = src->rank; dst->world = src->world;
     dst->tables_dirty = true; dst->lists_dirty = true; dst->shard_dirty = true; dst->ref_valid = false;
@@ -1032,6 +1037,16 @@ int vrt_hip_set_table_budget(vrt_hip_ctx *c, float budget)
     if (!(budget > 0.f)) return fail(c, VRT_HIP_ERR_INVALID, "set_table_budget: the budget must be positive (INFINITY = unchecked)");
     if (budget != c->table_budget) c->reset_seq = c->frame_seq;
     c->table_budget = budget;
+    ++c->state_gen;
+    return VRT_HIP_OK;
+}
+
+int vrt_hip_set_cull_prune(vrt_hip_ctx *c, float kappa)
+{
+    if (!c) return VRT_HIP_ERR_INVALID;
+    if (!(kappa >= 0.f)) return fail(c, VRT_HIP_ERR_INVALID, "set_cull_prune: the factor must be >= 0 (0 = off)");
+    if (kappa != c->cull_prune) c->reset_seq = c->frame_seq;
+    c->cull_prune = kappa;
     ++c->state_gen;
     return VRT_HIP_OK;
 }
@@ -1483,7 +1498,7 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
         for (int k = 0; k < i; ++k)
             if (ctxs[k] == c) return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: a context holds ONE frame's lists and queues -- every frame of a batch needs its own");
         if (c->device != c0->device || c->exp_kind != c0->exp_kind || c->erf_kind != c0->erf_kind || c->dense_waves != c0->dense_waves ||
-            c->table_hx != c0->table_hx || c->table_budget != c0->table_budget)
+            c->table_hx != c0->table_hx || c->table_budget != c0->table_budget || c->cull_prune != c0->cull_prune || c->cull_eps != c0->cull_eps)
             return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the contexts differ in device or in Exp / Erf / dense-kernel / table options");
         if (c->w != c0->w || c->h != c0->h || c->n != c0->n || c->rank != c0->rank || c->world != c0->world)
             return fail(c0, VRT_HIP_ERR_INVALID, "frame_batch: the frames differ in image size, scene size or shard");

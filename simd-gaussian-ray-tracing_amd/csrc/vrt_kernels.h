@@ -78,6 +78,7 @@ struct CellGrid {
     uint32_t *overflow, *n_overflow; // blocks (cell*16 + block) whose per-ray lists outgrew the one-wave kernel's
                                      // LDS slots: it hands them to the dense kernel, which runs after it
     uint32_t dense_threshold;        // a cell whose list is longer than this goes to the dense queue
+    float prune_budget;              // block kernel: a ray may drop the smallest entries of its list while their sum (units of the tile level's eps) stays below this (prune_list; 0 = off)
     int pair_lanes;                  // block kernel: blocks with short per-ray lists are shaded with (ray, emitter) pairs as lanes (shade_pairs)
     // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame (written by the one-wave kernel),
     // [2] = items (blocks) the dense kernel found in its queues, [3] = sequence number of the frame that wrote [2]

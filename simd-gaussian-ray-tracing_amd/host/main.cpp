@@ -51,6 +51,8 @@ static const char *const HELP_MSG =
     "                            (coarser where the kernel's own error bound leaves room) and interpolate; every ray stays\n"
     "                            within --table-budget of the exact sum or its block is shaded exactly (0.05; 0 = exact only)\n"
     "      --table-budget B      largest worst-case change of a ray's radiance the table may cause (2.5e-5)\n"
+    "      --cull-prune K        budget factor of the ray-level prune: a ray drops its smallest entries while their sum stays\n"
+    "                            below K * 1365 * cull-eps (6; 0 = off)\n"
     "      --help                this text\n";
 
 struct cmd_args_t { // main.cpp:54-184
@@ -59,7 +61,7 @@ struct cmd_args_t { // main.cpp:54-184
     char *outfile = nullptr, *infile = nullptr;
     bool use_grid = false;
     u64 thread_count = 1, nr_frames = 1, tiles = 16, mode = 8;
-    f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f, table_step = 0.05f, table_budget = 2.5e-5f;
+    f32 rot = 360.f, inital_rot = 0.f, camera_offset = -4.f, focal_length = 1.f, cull_eps = 1e-9f, table_step = 0.05f, table_budget = 2.5e-5f, cull_prune = 6.f;
     bool plane_arrays = false;
     u64 gpus = 1;
     cmd_args_t(int argc, char **argv)
@@ -73,7 +75,7 @@ struct cmd_args_t { // main.cpp:54-184
             { "rotation", required_argument, NULL, 'r' }, { "initial-rotation", required_argument, NULL, 'i' },
             { "camera-offset", required_argument, NULL, 'c' }, { "focal-length", required_argument, NULL, 0xfe },
             { "help", no_argument, NULL, 0xff }, { "plane-arrays", no_argument, NULL, 0xfd },
-            { "cull-eps", required_argument, NULL, 0xfc }, { "table-step", required_argument, NULL, 0xfb }, { "table-budget", required_argument, NULL, 0xf9 },
+            { "cull-eps", required_argument, NULL, 0xfc }, { "table-step", required_argument, NULL, 0xfb }, { "table-budget", required_argument, NULL, 0xf9 }, { "cull-prune", required_argument, NULL, 0xf8 },
             { "gpus", required_argument, NULL, 0xfa },
             { NULL, 0, NULL, 0 }
         };
@@ -100,6 +102,7 @@ struct cmd_args_t { // main.cpp:54-184
             case 0xfc: cull_eps = strtof(optarg, NULL); break;
             case 0xfb: table_step = strtof(optarg, NULL); break;
             case 0xf9: table_budget = strtof(optarg, NULL); break;
+            case 0xf8: cull_prune = strtof(optarg, NULL); break;
             case 0xfa: gpus = strtoul(optarg, NULL, 10); break;
             case 'm': mode = strtoul(optarg, NULL, 10); if (mode < 1 || mode > 8) mode = 8; break;
             default: break;
@@ -159,6 +162,7 @@ static int run_on_group(const cmd_args_t &cmd, const std::vector<vrt::gaussian_t
         chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options", ctx);
         chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step", ctx);
         chk(vrt_hip_set_table_budget(ctx, cmd.table_budget), "set_table_budget", ctx);
+        chk(vrt_hip_set_cull_prune(ctx, cmd.cull_prune), "set_cull_prune", ctx);
         if (deal_frames) chk(vrt_hip_set_shard(ctx, 0, 1), "set_shard", ctx); // every member renders whole frames
     }
     const u64 width = cmd.w, height = cmd.h;
@@ -329,6 +333,7 @@ int main(int argc, char **argv)
         chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options");
         chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step");
         chk(vrt_hip_set_table_budget(ctx, cmd.table_budget), "set_table_budget");
+        chk(vrt_hip_set_cull_prune(ctx, cmd.cull_prune), "set_cull_prune");
     }
 
     const u64 width = cmd.w, height = cmd.h;

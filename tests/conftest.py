@@ -51,6 +51,7 @@ def renderer(pkg, _shared_renderer):
     to the exact kernels or another step must not leak that into the next test)."""
     _shared_renderer.set_table_step(pkg.TABLE_STEP_DEFAULT)
     _shared_renderer.set_table_budget(2.5e-5)
+    _shared_renderer.set_cull_prune(6.0)
     return _shared_renderer
 
 

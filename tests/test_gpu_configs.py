@@ -73,11 +73,15 @@ def oracle_pixels(oracle, g, w, h, rot, pix, tiles_n=16):
     return oracle.render(w, h, oracle.camera_plane(cam), cam.position[:], g, tiles, pixels=pix, want_image=False)[1]
 
 
-@pytest.mark.parametrize("w,rot,npix", [(512, 0.0, 48), (512, 33.0, 48), (2048, 0.0, 32), (2048, 123.0, 32)])
-def test_cfg3_teapot_exact_kernels_vs_oracle(pkg, oracle, renderer, w, rot, npix):
-    """-f test-objects/teapot.obj -w 2048 (BASELINE configs[2]) and its 512^2 sibling: DEFAULT (exact) kernels, no table
-    mode; 3644 Gaussians of sigma .05 -- the small-sigma case where a last-bit ray difference is worth 5e-4."""
+@pytest.mark.parametrize("w,rot,npix,table", [(512, 0.0, 96, None), (512, 33.0, 96, 0.0), (2048, 0.0, 256, None), (2048, 123.0, 256, None),
+                                              (2048, 123.0, 64, 0.0)])
+def test_cfg3_teapot_exact_kernels_vs_oracle(pkg, oracle, renderer, w, rot, npix, table):
+    """-f test-objects/teapot.obj -w 2048 (BASELINE configs[2]) and its 512^2 sibling, at the DEFAULT settings (dense blocks
+    through the table kernel, round 3) and with `--table-step 0` (exact kernels); 3644 Gaussians of sigma .05 -- the
+    small-sigma case where a last-bit ray difference is worth 5e-4."""
     g = oracle.read_obj(os.path.join(OBJ, "teapot.obj"))
+    if table is not None:
+        renderer.set_table_step(table)
     img, rad = product_frame(pkg, renderer, g, w, w, rot)
     pix, lit = lit_pixels(rad, npix, seed=300 + w + int(rot))
     orad = oracle_pixels(oracle, g, w, w, rot, pix)
@@ -106,13 +110,14 @@ def test_cfg4_grid64_2048_lit_pixels(pkg, oracle, renderer, rot):
     assert (lum == 0).mean() > 0.5
 
 
-@pytest.mark.parametrize("rot", [0.0, 150.0])
-def test_cfg5_monkey_4096_vs_oracle(pkg, oracle, renderer, rot):
-    """-f test-objects/monkey.obj -w 4096 (BASELINE configs[4]), first frame and one from the far side of the orbit."""
+@pytest.mark.parametrize("rot,npix", [(0.0, 192), (150.0, 192), (270.0, 96)])
+def test_cfg5_monkey_4096_vs_oracle(pkg, oracle, renderer, rot, npix):
+    """-f test-objects/monkey.obj -w 4096 (BASELINE configs[4]) at the default settings: first frame, one from the far side
+    of the orbit and one from the side."""
     w = 4096
     g = oracle.read_obj(os.path.join(OBJ, "monkey.obj"))
     img, rad = product_frame(pkg, renderer, g, w, w, rot)
-    pix, _ = lit_pixels(rad, 32, seed=500 + int(rot))
+    pix, _ = lit_pixels(rad, npix, seed=500 + int(rot))
     orad = oracle_pixels(oracle, g, w, w, rot, pix)
     err = np.abs(rad.reshape(-1, 4)[pix] - orad).max()
     assert err <= TOL, err

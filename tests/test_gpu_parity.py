@@ -625,10 +625,11 @@ def test_per_tile_cull_slack_keeps_the_error_bound(pkg, oracle, renderer, monkey
     g = scene.grid_scene(64) if name == "g64" else scene.read_obj(os.path.join(GOLDEN, "test-objects", name + ".obj"))
     cam, _ = scene.cli_camera(w, w, initial_rot=rot)
 
-    def frame(r, eps):
+    def frame(r, eps, kappa=0.0):
         r.set_gaussians(g)
         r.set_camera_view(w, w, cam.view)
         r.set_options(pkg.EXP_VCL, pkg.ERF_AS, eps)
+        r.set_cull_prune(kappa)
         r.set_table_step(0.0)   # the exact kernels: this test is about what the CULL loses (the table kernel has its own budget)
         r.tile_gaussians(2 / 16, 2 / 16, cam.view)
         r.enable_stats(True)
@@ -639,6 +640,9 @@ def test_per_tile_cull_slack_keeps_the_error_bound(pkg, oracle, renderer, monkey
 
     full, _ = frame(renderer, 0.0)
     rad, work = frame(renderer, 1e-9)
+    # the budgeted ray-level prune on top (round 3, default kappa 6): a block-kernel ray may lose 3 * 6 * 1365 * cull_eps = 2.46e-5 more --
+    # for it this replaces the table budget, so a frame's worst case stays 5e-5 -- and shades fewer entries for it
+    radp, workp = frame(renderer, 1e-9, 6.0)
     monkeypatch.setenv("VRT_HIP_CULL_REF_N", "0")
     r0 = pkg.Renderer(0)
     try:
@@ -647,9 +651,12 @@ def test_per_tile_cull_slack_keeps_the_error_bound(pkg, oracle, renderer, monkey
         r0.close()
         renderer.set_options(pkg.EXP_VCL, pkg.ERF_AS, 1e-9)
         renderer.set_table_step(pkg.TABLE_STEP_DEFAULT)
+        renderer.set_cull_prune(6.0)
     assert np.abs(rad - full).max() <= 2.5e-5
     assert np.abs(rad0 - full).max() <= np.abs(rad - full).max() + 1e-6
     assert work < work0
+    assert np.abs(radp - full).max() <= 5e-5 and np.abs(radp - rad).max() <= 2.46e-5
+    assert workp <= work and (name != "g64" or workp < work)   # (at 1024^2 most of this scene's blocks are dense: the prune is the block kernel's)
 
 
 def test_kernel_timing_modes(pkg, oracle, renderer):
