@@ -448,6 +448,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     }
     c->cells_x = (geo.tile_w + CELL - 1) / CELL; c->cells_y = (geo.tile_h + CELL - 1) / CELL;
     c->n_cells = n_local * c->cells_x * c->cells_y;
+    if (c->n_cells > ACTIVE_CELL_MASK) return fail(c, VRT_HIP_ERR_INVALID, "tile grid: more than 2^24 cells of 32 x 32 pixels on one device");
     c->cstride = std::max(1u, std::min(c->n, 4096u));
     HIPCHK(c, c->c_count.reserve(c->n_cells)); HIPCHK(c, c->c_active.reserve(c->n_cells));
     HIPCHK(c, c->c_dense.reserve(c->n_cells));

@@ -23,6 +23,7 @@ constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four pa
 #define VRT_DCAP 1024
 #endif
 constexpr int DCAP = VRT_DCAP;        // per-block candidates the dense kernel keeps in LDS (61 KB with the rest; measured: no change below 64 KB, +4 % at 81 KB, +10 % at 104 KB)
+constexpr uint32_t ACTIVE_COUNT_SHIFT = 24, ACTIVE_CELL_MASK = 0xFFFFFFu; // CellGrid::active entries: cell id | min(list length, 255) << 24
 constexpr int PL = VRT_PL;        // per-lane list capacity (u8 positions into the block's candidates)
 
 // Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
@@ -61,7 +62,7 @@ struct CellGrid {
     uint32_t *count;                 // [cells]; 0xFFFFFFFF = overflowed its slot: use the tile's list
     uint32_t *indices;               // cell c at indices + c*cstride
     uint32_t n_cells;                // cells of all local tiles
-    uint32_t *active;                // cell ids with short lists: shaded one wavefront per block
+    uint32_t *active;                // cells with short lists (shaded one wavefront per block): cell id | list length << 24 (ACTIVE_COUNT_SHIFT)
     uint32_t *dense;                 // cell ids with long lists: shaded one 16-wave workgroup per block
     uint32_t *scratch;               // dense kernel: cstride words per workgroup (a block's survivors when they outgrow LDS)
     uint32_t *dense_sorted;          // the same, longest list first (order_dense_kernel): the queue order of the dense kernel

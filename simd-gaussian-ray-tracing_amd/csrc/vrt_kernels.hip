@@ -696,6 +696,11 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wave = blockIdx.x, G = gridDim.x;
     const bool first = threadIdx.x == 0;
     const uint64_t npix = (uint64_t)R.width * R.height;
+    // A block's way to its candidates is a chain of dependent loads (queue entry -> list -> parameter rows), and at the start of a launch
+    // every wave walks it at the same time, with nothing to hide it behind.  Two links are taken out: an entry of the active queue carries
+    // its cell's list length in its top byte (ACTIVE_COUNT_SHIFT), and the entry of a wave's static first block is fetched together with
+    // the counters it is checked against (stale beyond n_active: used only below it).
+    const uint32_t spec_entry = C.n_cells ? C.active[min(wave >> 4, C.n_cells - 1u)] : 0u;
     const uint32_t n_active = *C.n_active, n_dense_cells = *C.n_dense;
     if (C.feedback && wave == 0 && first) {
         __hip_atomic_store(&C.feedback[0], n_dense_cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -766,7 +771,8 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     for (uint32_t item = wave; item < n_shade; item = next_item()) {
         const unsigned long long tl0 = O.timeline ? wall_clock64() : 0ull; // diagnostics (VRT_HIP_TIMELINE runs only)
         const uint32_t ci = item >> 4;
-        const uint32_t cell = C.active[ci < n_active ? ci : C.n_cells - 1u - (ci - n_active)];
+        const uint32_t entry = (item == wave && ci < n_active) ? spec_entry : C.active[ci < n_active ? ci : C.n_cells - 1u - (ci - n_active)];
+        const uint32_t cell = entry & ACTIVE_CELL_MASK;
         const uint32_t bi = item & 15u;
         const BlockPos p = block_of(T, C, O, cell, bi, lane);
         if (!p.inside) continue;
@@ -778,7 +784,8 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         const uint64_t out = out_index(T, C, O, cell, bi, lane, p, pix, n_active);
 
         // the cell's candidate list (or, if it overflowed its slot, the tile's)
-        uint32_t n_list = C.count[cell];
+        uint32_t n_list = entry >> ACTIVE_COUNT_SHIFT;
+        if (n_list == 255u) n_list = C.count[cell]; // a list length that does not fit the byte
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
         if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
 
@@ -2251,13 +2258,14 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         }
         if (lane == 0) {
             C.count[cell] = ctotal;
-            s_flag[ci] = ctotal ? (ctotal > C.dense_threshold ? 3u : (ctotal <= C.light_threshold ? 5u : 1u)) : 0u;
+            s_flag[ci] = (ctotal ? (ctotal > C.dense_threshold ? 3u : (ctotal <= C.light_threshold ? 5u : 1u)) : 0u) | (min(ctotal, 255u) << 8);
         }
     }
     __syncthreads();
     if (tl) tl[3] = wall_clock64();
     if (wave == 0) { // cpt <= 64: one flag per lane
-        const uint32_t mine = lane < cpt ? s_flag[lane] : 2u;
+        const uint32_t flag = lane < cpt ? s_flag[lane] : 2u;
+        const uint32_t mine = flag & 0xFFu, packed_count = (flag >> 8) << ACTIVE_COUNT_SHIFT; // the list length rides in the queue entry
         const unsigned long long m_act = __ballot(mine == 1u), m_dense = __ballot(mine == 3u);
         const unsigned long long m_light = __ballot(mine == 5u);
         // Retained frame buffer (RenderTarget::stamp): the buffer still holds this context's previous frame, so an empty cell
@@ -2284,11 +2292,11 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         const uint32_t cell = lt * cpt + lane;
         if (mine == 1u) {
             const uint32_t pos = base_a + (uint32_t)__popcll(m_act & below);
-            C.active[pos] = cell;
+            C.active[pos] = cell | packed_count;
             if (C.slot) C.slot[cell] = pos;
             if (F.O.sparse) F.O.keys[pos] = t * cpt + lane;
         } else if (mine == 5u) { // light: from the back of the active queue (raster frames only: no slot, no key)
-            C.active[C.n_cells - 1u - (base_l + (uint32_t)__popcll(m_light & below))] = cell;
+            C.active[C.n_cells - 1u - (base_l + (uint32_t)__popcll(m_light & below))] = cell | packed_count;
         } else if (mine == 3u) {
             const uint32_t pos = base_d + (uint32_t)__popcll(m_dense & below);
             C.dense[pos] = cell;
@@ -2415,6 +2423,7 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
         if (lane == 0) C.count[cell] = total > C.cstride ? 0xFFFFFFFFu : total;
     }
     if (lane == 0) s_flag[wave] = cell < n_cells ? (total ? (total > C.dense_threshold ? 3u : 1u) : 0u) : 2u;
+    const uint32_t packed_count = min(total, 255u) << ACTIVE_COUNT_SHIFT;
     __syncthreads();
     if (tid == 0) {
         uint32_t na = 0, nd = 0;
@@ -2428,7 +2437,7 @@ __global__ __launch_bounds__(1024) void build_cell_lists_kernel(SceneTables S, T
         const uint32_t mine = s_flag[wave];
         for (uint32_t w = 0; w < wave; ++w) before += s_flag[w] == mine;
         if (mine == 1u) {
-            C.active[s_base[0] + before] = cell;
+            C.active[s_base[0] + before] = cell | packed_count;
             if (C.slot) C.slot[cell] = s_base[0] + before;
             if (keys) {
                 const uint32_t cpt = C.cells_x * C.cells_y, lt = cell / cpt;
