@@ -19,6 +19,7 @@
 //   * two shading kernels -- one wavefront per 8x8 block with per-ray candidate lists (sparse scenes), one
 //     16-wave workgroup per block with depth-sorted candidates and exact saturation skipping (dense scenes).
 // DESIGN.md section 4 has the table of kernels and their measured costs.
+#include <hip/hip_fp16.h>
 #include "vrt_kernels.h"
 #include "vrt_device_math.h"
 
@@ -633,24 +634,18 @@ __device__ __forceinline__ void shade_range(const float4 *s_A, const float4 *s_B
 // below eps * 1365 / n, as if all n sat just under it.  A ray's own list knows better: what it lost is the SUM of sigma*mag*exp(-x) over
 // what it dropped, and on a grid scene one or two of a ray's five entries carry 1e-7 .. 1e-6 while the worst case reserves room for
 // dozens.  So after the unconditional pass the lane looks at the entries it kept (e_k = sigma*mag*exp(-x_k) in units of the tile
-// level's eps) and drops the smallest ones as long as their sum stays inside `budget` (CellGrid::prune_budget = kappa * 1365 eps:
+// level's eps; the pass leaves ln e_k = cull_x - x_k in LDS, as fp16 rounded up) and drops the smallest ones as long as their sum stays inside `budget` (CellGrid::prune_budget = kappa * 1365 eps:
 // 3 * that is what the ray's radiance can change by): smallest first, exactly -- entry k goes iff the sum of all
 // entries not larger than it fits.  Entries whose threshold sits at the Exp floor (cull_eps = 0, huge magnitudes) are never dropped.
 // A function of the block's survivors alone, so every path that must give identical bits still does.  `-g 64 -w 2048`: per-ray lists
 // 3.9 -> 2.5, the block's longest 5.4 -> 3.6; the pair loops are quadratic in that.
+constexpr uint32_t PRUNE_PL = 16; // lists up to this long are pruned; s_t holds ln(e_k) of their entries (fp16, rounded up)
 template <int N>
-__device__ __forceinline__ uint32_t prune_list(const float4 *s_A, const float4 *s_B, uint8_t *s_lane, uint32_t nl, uint32_t lane,
-                                               const LaneRay &ray, float floor_x, float budget)
+__device__ __forceinline__ uint32_t prune_list(const __half *s_t, uint8_t *s_lane, uint32_t nl, uint32_t lane, float budget)
 {
     float e[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const uint32_t j = (uint32_t)k < nl ? s_lane[k * 64 + lane] : 0u;
-        const float4 a = s_A[j], bq = s_B[j];
-        const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
-        const float x = sub_ref(a.w, mul_ref(mubar, mubar)) * bq.y;
-        e[k] = ((uint32_t)k < nl && bq.w < floor_x) ? __expf(bq.w - x) : INFINITY;
-    }
+    for (int k = 0; k < N; ++k) e[k] = (uint32_t)k < nl ? __expf(__half2float(s_t[k * 64 + lane])) : INFINITY;
     float least = e[0];
 #pragma unroll
     for (int k = 1; k < N; ++k) least = fminf(least, e[k]);
@@ -688,6 +683,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     __shared__ float4 s_A[PCAP], s_B[PCAP], s_M[PCAP], s_C[PCAP];
     __shared__ float s_q[PCAP];
     __shared__ uint8_t s_lane[PL * 64];
+    __shared__ __half s_t[NW == 1 ? PRUNE_PL * 64 : 1]; // ln(sigma*mag*exp(-x) / eps) of the first PRUNE_PL entries of every lane's list (prune_list)
 #ifdef VRT_PAIR_LANES
     __shared__ float4 s_pre[NW == 1 ? 128 : 1]; // pair lanes: the rays' (A, m, E, r) of the current and the next absorber slot
 #endif
@@ -737,30 +733,47 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     // ---- shade ----
     if (wave == 0 && threadIdx.x < RQ_N) C.rq_next[threadIdx.x * RQ_STRIDE] = 0;
     const uint32_t n_dyn = n_shade > G ? n_shade - G : 0u;
-    uint32_t rq_tries = 0;
+    uint32_t rq_tries = 0, rq_dead = 0; // rq_dead: queues this wave has seen run out (bit l = the l-th from its own)
     // next block: blocks cost between ~1 and ~30 units (the pair loops are quadratic in the per-ray list length), so
     // after its static first block a workgroup pulls more from the queues, its own first, until all are empty
     auto next_item = [&]() -> uint32_t {
-        while (rq_tries < RQ_N) {
-            const uint32_t q = (wave + rq_tries) % RQ_N;
-            const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
-            uint32_t m = 0xFFFFFFFFu;
-            if (first && per) {
-                uint32_t *ctr = C.rq + q * RQ_STRIDE;
-                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) m = atomicAdd(ctr, 1u);
-            }
-            if constexpr (NW == 1) {
+        if constexpr (NW == 1) {
+            // all RQ_N counters are looked at in ONE round trip (lane l reads the l-th queue from the wave's own on): a wave that is done
+            // leaves after one load instead of after RQ_N dependent ones -- at the end of a launch that was 5 us of every wave's exit
+            while (true) {
+                const uint32_t q = (wave + lane) % RQ_N;
+                const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
+                bool have = false;
+                if (lane < RQ_N && per && !((rq_dead >> lane) & 1u)) have = __hip_atomic_load(C.rq + q * RQ_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per;
+                const unsigned long long mask = __ballot(have);
+                if (!mask) return 0xFFFFFFFFu;
+                const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+                const uint32_t ql = (wave + l) % RQ_N, perl = (n_dyn - ql + RQ_N - 1) / RQ_N;
+                uint32_t m = 0xFFFFFFFFu;
+                if (first) m = atomicAdd(C.rq + ql * RQ_STRIDE, 1u);
                 m = __builtin_amdgcn_readfirstlane(m);
-            } else { // both waves take the same item: through LDS
+                if (m < perl) return G + ql + RQ_N * m;
+                rq_dead |= 1u << l; // lost the race for its last entry: that queue is empty for good, so at most RQ_N rounds
+            }
+        } else {
+            while (rq_tries < RQ_N) {
+                const uint32_t q = (wave + rq_tries) % RQ_N;
+                const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
+                uint32_t m = 0xFFFFFFFFu;
+                if (first && per) {
+                    uint32_t *ctr = C.rq + q * RQ_STRIDE;
+                    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) m = atomicAdd(ctr, 1u);
+                }
+                // both waves take the same item: through LDS
                 if (first) s_item = m;
                 __syncthreads();
                 m = s_item;
                 __syncthreads();
+                if (m < per) return G + q + RQ_N * m;
+                ++rq_tries;
             }
-            if (m < per) return G + q + RQ_N * m;
-            ++rq_tries;
+            return 0xFFFFFFFFu;
         }
-        return 0xFFFFFFFFu;
     };
     auto write_block = [&](float Lr, float Lg, float Lb, float La, bool valid, uint64_t out) {
         if (valid) {
@@ -848,6 +861,12 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
                 const float x = sub_ref(a.w, mul_ref(mubar, mubar)) * bq.y;
                 if (!(x > slack_cull_x(bq.w, slack_r, T.floor_x))) {
                     if (nl < PL && wv == 0) s_lane[nl * 64 + lane] = (uint8_t)j;
+                    if constexpr (NW == 1) {
+                        if (nl < PRUNE_PL) { // fp16 rounds to nearest within 2^-11: the bias keeps the stored value above the true one
+                            const float t = bq.w - x;
+                            s_t[nl * 64 + lane] = __float2half(bq.w < T.floor_x ? t + 0.001f * fabsf(t) + 1e-4f : INFINITY);
+                        }
+                    }
                     ++nl;
                 }
             }
@@ -872,10 +891,20 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
         if constexpr (NW == 1) {
-            if (C.prune_budget > 0.f && nmax <= 16u) {
-                if (nmax <= 4u) nl = prune_list<4>(s_A, s_B, s_lane, nl, lane, ray, T.floor_x, C.prune_budget);
-                else if (nmax <= 8u) nl = prune_list<8>(s_A, s_B, s_lane, nl, lane, ray, T.floor_x, C.prune_budget);
-                else nl = prune_list<16>(s_A, s_B, s_lane, nl, lane, ray, T.floor_x, C.prune_budget);
+            if (C.prune_budget > 0.f && nmax <= PRUNE_PL) {
+                switch (nmax) { // exactly as many entries as the block's longest list has, while that is cheap
+                case 0: break;
+                case 1: nl = prune_list<1>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 2: nl = prune_list<2>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 3: nl = prune_list<3>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 4: nl = prune_list<4>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 5: nl = prune_list<5>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 6: nl = prune_list<6>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 7: nl = prune_list<7>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 8: nl = prune_list<8>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                case 9: case 10: case 11: case 12: nl = prune_list<12>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                default: nl = prune_list<16>(s_t, s_lane, nl, lane, C.prune_budget); break;
+                }
                 nmax = nl;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));

@@ -21,6 +21,7 @@ find $OUT/stats_serial -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_20steps.json 2>> $OUT/bench.log
 python3 bench.py --frames-in-flight 1 --no-cpu-baseline > $OUT/bench_serial.json 2>> $OUT/bench.log
+python3 tools/timeline.py 64 2048 2> $OUT/timeline.txt > /dev/null
 echo "bench done"
 # --- OBJ scenes: stats + instruction counters, default table mode and exact ---
 cd /tmp
