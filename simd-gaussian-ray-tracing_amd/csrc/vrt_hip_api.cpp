@@ -64,6 +64,8 @@ struct vrt_hip_ctx {
     DevBuf<float> soa[9]; // mu_x mu_y mu_z ar ag ab aa sigma mag
     bool has_alpha = false;
     DevBuf<float4> mu_sig, gA, gB, gC, gD;
+    DevBuf<float4> gChunk;       // bounding spheres of every 64 consecutive Gaussians (launch_build_chunks): the tile level tests these first
+    int use_chunks = 1;          // VRT_HIP_CHUNKS: 0 every tile tests every Gaussian (rounds 1-2); 1 (default) chunks first for scenes beyond 8192 Gaussians; 2 always
     DevBuf<uint32_t> iota;
     bool tables_dirty = true;
     bool gA_valid = false;
@@ -258,6 +260,8 @@ int rebuild_tables(vrt_hip_ctx *c)
     launch_build_static(c->n, c->soa[0].p, c->soa[1].p, c->soa[2].p, c->soa[3].p, c->soa[4].p, c->soa[5].p,
                         c->has_alpha ? c->soa[6].p : nullptr, c->soa[7].p, c->soa[8].p, eps_eff,
                         exp_floor_x(c->exp_kind), c->mu_sig.p, c->gB.p, c->gC.p, c->gD.p, c->stream);
+    HIPCHK(c, c->gChunk.reserve((c->n + 63u) / 64u));
+    launch_build_chunks(c->n, c->mu_sig.p, c->gB.p, c->gChunk.p, c->stream);
     launch_iota(c->iota.p, c->n, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream)); // later launches may use a caller's stream
@@ -365,6 +369,8 @@ BinArgs bin_args(const vrt_hip_ctx *c)
 {
     BinArgs a{};
     a.mu_sig = c->mu_sig.p; a.gA = c->gA.p; a.gB = c->gB.p; a.n = c->n;
+    // the chunk test costs a round trip of its own (the rows can only be asked for after it): worth it where the per-Gaussian pass is long
+    a.chunks = (c->use_chunks == 2 || (c->use_chunks == 1 && c->n > 8192u)) ? c->gChunk.p : nullptr;
     for (int i = 0; i < 16; ++i) a.V.m[i] = c->view[i];
     a.xc = c->xc.p; a.yc = c->yc.p; a.tw = c->tw; a.th = c->th; a.tiles_w = c->tiles_w;
     return a;
@@ -868,6 +874,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
     }
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
+    if (const char *e = getenv("VRT_HIP_CHUNKS")) c->use_chunks = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("VRT_HIP_CULL_PRUNE")) c->cull_prune = fmaxf(0.f, (float)atof(e));
     if (const char *e = getenv("VRT_HIP_TABLE_STEP")) { const float v = (float)atof(e); if (v >= 0.f && v <= 1.f) c->table_hx = v; }
     if (const char *e = getenv("VRT_HIP_TABLE_ROOM")) { const float v = (float)atof(e); if (v > 0.f && v <= 10.f) c->table_room = v; }

@@ -10,6 +10,7 @@ constexpr int BLOCK_W = 8;        // one wavefront = one 8x8 pixel block (64 ray
 constexpr int BLOCK_H = 8;
 constexpr int CELL = 32;          // second-level cull region: 32x32 pixels = 4x4 blocks
 constexpr int TCAP = 1024;        // a tile's candidates kept in LDS by the fused list kernel
+constexpr int CH_CAP = 2048;       // chunks of 64 Gaussians a tile may keep after the chunk test (more: every Gaussian is tested, as before round 3)
 constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate cell kernel (one wave per cell)
 #ifndef VRT_PCAP
 #define VRT_PCAP 96
@@ -173,6 +174,7 @@ struct Mat4 { float m[16]; };
 struct BinArgs {
     const float4 *mu_sig, *gA, *gB;
     uint32_t n;
+    const float4 *chunks;            // nullable: bounding sphere (centre, radius incl. the members' reach) of every 64 consecutive Gaussians (launch_build_chunks)
     // input: caller-made lists (from_list) ...
     const uint32_t *in_start, *in_count, *in_indices;
     // ... or on-device binning with the reference's test
@@ -206,6 +208,7 @@ struct FuseArgs {
     unsigned long long *timeline; // nullable diagnostics: 8 wall_clock64 stamps per tile workgroup
 };
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st);
+void launch_build_chunks(uint32_t n, const float4 *mu_sig, const float4 *gB, float4 *chunks, hipStream_t st);
 void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uint32_t cells_y, float4 *cones_out, hipStream_t st);
 
 // Several frames per launch (vrt_hip_frame_batch_device): what one frame's three kernels take, as a row of a device array;

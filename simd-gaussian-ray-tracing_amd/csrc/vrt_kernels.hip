@@ -2130,6 +2130,48 @@ void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uin
     if (n) hipLaunchKernelGGL(tile_cones_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a, a.tiles_w * tiles_h, cells_x, cells_y, cones_out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chunk table (round 3): every 64 consecutive Gaussians get a bounding sphere whose radius includes the members' reach -- the distance
+// beyond which cone_keeps drops them: x = d^2 / (2 sigma^2) with 0.999 x - 1e-3 > cull_x.  cone_keeps' lower bound of the distance
+// between a point and the rays of a cone is 1-Lipschitz in the point, so a cone farther than the radius from the chunk's centre keeps
+// none of its members: the tile level then tests N / 64 spheres and the members of the chunks that are left instead of all N Gaussians
+// (256 tiles x 4096 x 32 B = 33 MB of L2 reads per `-g 64 -w 2048` frame before: the level ran at L2 bandwidth).  Index order is kept (chunks in
+// order, members in order), so the lists are the same lists.  Depends on the scene and cull_eps only: built with the static tables.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_chunks_kernel(uint32_t n, const float4 *__restrict__ mu_sig, const float4 *__restrict__ gB, float4 *__restrict__ chunks)
+{
+    const uint32_t lane = threadIdx.x & 63u, chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (chunk * 64u >= n) return;
+    const uint32_t i = chunk * 64u + lane;
+    const bool valid = i < n;
+    const float4 p = valid ? mu_sig[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bq = valid ? gB[i] : make_float4(0.f, 1.f, 0.f, -INFINITY);
+    const float lo_x = wave_min(valid ? p.x : INFINITY), hi_x = wave_max(valid ? p.x : -INFINITY);
+    const float lo_y = wave_min(valid ? p.y : INFINITY), hi_y = wave_max(valid ? p.y : -INFINITY);
+    const float lo_z = wave_min(valid ? p.z : INFINITY), hi_z = wave_max(valid ? p.z : -INFINITY);
+    const float mx = 0.5f * (lo_x + hi_x), my = 0.5f * (lo_y + hi_y), mz = 0.5f * (lo_z + hi_z);
+    const float dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+    const float xr = bq.w + 1e-3f; // kept iff 0.999 d^2 bq.y - 1e-3 <= cull_x
+    const float reach = xr > 0.f ? sqrtf(xr / (0.999f * bq.y)) : 0.f;
+    float rho = wave_max(valid ? sqrtf(dx * dx + dy * dy + dz * dz) + reach : 0.f);
+    rho = rho * 1.0001f + 1e-6f * (1.f + fabsf(mx) + fabsf(my) + fabsf(mz));
+    if (lane == 0) chunks[chunk] = make_float4(mx, my, mz, rho);
+}
+void launch_build_chunks(uint32_t n, const float4 *mu_sig, const float4 *gB, float4 *chunks, hipStream_t st)
+{
+    const uint32_t nch = (n + 63u) / 64u;
+    if (nch) hipLaunchKernelGGL(build_chunks_kernel, dim3((nch + 3u) / 4u), dim3(256), 0, st, n, mu_sig, gB, chunks);
+}
+__device__ __forceinline__ bool chunk_keeps(const Cone &k, float4 ch, float ox, float oy, float oz)
+{
+    const float ax = ch.x - ox, ay = ch.y - oy, az = ch.z - oz;
+    const float d2 = ax * ax + ay * ay + az * az;
+    const float tc = ax * k.cx + ay * k.cy + az * k.cz;
+    const float dperp = __builtin_amdgcn_sqrtf(fmaxf(0.f, d2 - tc * tc - 8e-6f * d2)); // the cancellation's rounding, on the keeping side
+    const float dmin = fmaxf(0.f, dperp * k.cos_t - fabsf(tc) * k.sin_t);
+    return !(dmin * 0.9999f > ch.w);
+}
+
 template <bool FROM_LIST>
 __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const FuseArgs &F)
 {
@@ -2138,6 +2180,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     __shared__ float4 s_A[TCAP], s_B[TCAP];
     __shared__ uint32_t s_flag[MAX_FUSED_CELLS], s_inact[MAX_FUSED_CELLS];
     __shared__ uint32_t s_base[4];
+    __shared__ uint32_t s_chunk[FROM_LIST ? 1 : CH_CAP];
     const uint32_t lt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t t = F.tile_map ? F.tile_map[lt] : lt;
     const uint32_t tx = t % P.tiles_w, ty = t / P.tiles_w;
@@ -2167,17 +2210,29 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     // (sub-pass u, wave, lane) lexicographic.
     bool keep[4];
     uint32_t idx[4];
-    float4 ga[4], gb[4];
+    float4 ga[4], gb[4], gm[4]; // gm: centre and sigma for the reference's tile test -- fetched with the other rows when the candidates are few (chunked)
+    // chunked: the candidates are the members of the chunks that passed the chunk test, one chunk per (sub-pass, wave) -- the same
+    // lexicographic (sub-pass, wave, lane) order as below, which is index order again
+    bool chunked = !FROM_LIST && P.refine && P.chunks != nullptr;
+    uint32_t n_slots = 0;
     auto fetch = [&](uint32_t base) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t k = base + u * 1024 + tid;
-            keep[u] = k < n_in;
-            idx[u] = keep[u] ? (FROM_LIST ? in_list[k] : k) : 0u;
+            if (!FROM_LIST && chunked) {
+                const uint32_t slot = base / 64u + u * 16u + wave;
+                idx[u] = slot < n_slots ? s_chunk[slot] * 64u + lane : 0xFFFFFFFFu;
+                keep[u] = idx[u] < n_in;
+                if (!keep[u]) idx[u] = 0u;
+            } else {
+                const uint32_t k = base + u * 1024 + tid;
+                keep[u] = k < n_in;
+                idx[u] = keep[u] ? (FROM_LIST ? in_list[k] : k) : 0u;
+            }
             if (keep[u] && (P.refine || F.enabled)) { ga[u] = P.gA[idx[u]]; gb[u] = P.gB[idx[u]]; }
+            if (!FROM_LIST && chunked && keep[u]) gm[u] = P.mu_sig[idx[u]];
         }
     };
-    fetch(0); // in flight while the cone is set up
+    if (!chunked) fetch(0); // in flight while the cone is set up
     // (b) tile cone from the centre and the four corner pixels of the tile (pinhole rays: the
     // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
     Cone cone = {};
@@ -2191,8 +2246,38 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         }
     }
 
+    if constexpr (!FROM_LIST) {
+        if (chunked) { // ---- chunk test: one sphere per thread and pass, order-preserving compaction of the chunk ids ----
+            const uint32_t nch = (n_in + 63u) / 64u;
+            const float ox = P.R.origin[0], oy = P.R.origin[1], oz = P.R.origin[2];
+            for (uint32_t cb = 0; cb < nch; cb += 1024) {
+                const uint32_t c = cb + tid;
+                const bool kc = c < nch && chunk_keeps(cone, P.chunks[c], ox, oy, oz);
+                const unsigned long long m = __ballot(kc);
+                if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(m);
+                __syncthreads();
+                const uint32_t v = lane < 16 ? s_wave_cnt[lane] : 0u;
+                uint32_t incl = v;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                    if (lane >= (uint32_t)off) incl += up;
+                }
+                const uint32_t before = (uint32_t)__shfl((int)(incl - v), (int)wave, 64);
+                if (kc) {
+                    const uint32_t pos = n_slots + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    if (pos < CH_CAP) s_chunk[pos] = c;
+                }
+                n_slots += (uint32_t)__shfl((int)incl, 15, 64);
+                __syncthreads();
+            }
+            if (n_slots > CH_CAP) chunked = false; // (wave-uniform) too many chunks for LDS: every Gaussian is a candidate
+            fetch(0);
+        }
+    }
     if (tl) tl[1] = wall_clock64();
-    for (uint32_t base = 0; base < n_in; base += 4096) {
+    const uint32_t n_cand = (!FROM_LIST && chunked) ? n_slots * 64u : n_in;
+    for (uint32_t base = 0; base < n_cand; base += 4096) {
         if (base) fetch(base);
         unsigned long long mask[4];
 #pragma unroll
@@ -2204,7 +2289,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
                 if (keep[u]) {
 #pragma clang fp contract(off)
                     keep[u] = false;
-                    const float4 g = P.mu_sig[idx[u]];
+                    const float4 g = chunked ? gm[u] : P.mu_sig[idx[u]];
                     // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
                     const float vx = (P.V.m[0] * g.x + P.V.m[4] * g.y) + (P.V.m[8] * g.z + P.V.m[12] * 1.f);
                     const float vy = (P.V.m[1] * g.x + P.V.m[5] * g.y) + (P.V.m[9] * g.z + P.V.m[13] * 1.f);

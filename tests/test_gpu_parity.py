@@ -988,3 +988,39 @@ def single_frame_ref(pkg, renderer, g, cam, w, tiles_n, pack):
     renderer.set_camera_view(w, w, cam.view)
     renderer.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, cam.view)
     return renderer.render(cam.position, pack, want_radiance=False)[0]
+
+
+def test_chunked_tile_level_gives_the_same_lists(pkg, oracle, monkeypatch):
+    """Round 3: for scenes beyond 8192 Gaussians the tile level tests the bounding spheres of 64 consecutive Gaussians first
+    (launch_build_chunks) and only the members of the chunks that are left.  The chunk test is conservative and keeps index order,
+    so the lists -- and with them every bit of the frame -- are the ones of the per-Gaussian pass (VRT_HIP_CHUNKS=0); forced on
+    (VRT_HIP_CHUNKS=2) the same holds for the small scenes."""
+    from sgrt_amd import scene
+    rng = np.random.default_rng(11)
+    n = 20000
+    cloud = np.zeros(n, scene.GAUSSIAN)
+    cloud["mu"][:, :3] = rng.normal(size=(n, 3)) * np.array([0.8, 0.8, 0.3]) + np.array([0, 0, 1])
+    cloud["mu"][:, 3] = 0
+    cloud["sigma"] = rng.uniform(0.004, 0.02, n); cloud["magnitude"] = rng.uniform(0.2, 2, n); cloud["albedo"] = rng.uniform(0, 1, (n, 4))
+    order = np.lexsort((cloud["mu"][:, 0], np.floor(cloud["mu"][:, 1] * 8)))   # rows of a coarse raster: chunks with some locality
+    cases = [("g64", scene.grid_scene(64), 1024, 47.0), ("teapot", scene.read_obj(os.path.join(GOLDEN, "test-objects", "teapot.obj")), 512, 20.0),
+             ("cloud", cloud[order], 768, 10.0), ("cloud unsorted", cloud, 512, 0.0)]
+    for name, g, w, rot in cases:
+        cam, _ = scene.cli_camera(w, w, initial_rot=rot)
+        out = {}
+        for mode in ("0", "2", "1"):
+            monkeypatch.setenv("VRT_HIP_CHUNKS", mode)
+            r = pkg.Renderer(0)
+            try:
+                r.set_gaussians(g); r.set_camera_view(w, w, cam.view); r.tile_gaussians(2 / 16, 2 / 16, cam.view)
+                r.enable_stats(True)
+                img, rad = r.render(cam.position)
+                st = r.stats()
+                out[mode] = (img, rad, st["tile_entries"], st["list_entries"])
+            finally:
+                r.close()
+        for mode in ("2", "1"):
+            assert out[mode][2:] == out["0"][2:], (name, mode, out[mode][2:], out["0"][2:])
+            np.testing.assert_array_equal(out[mode][0], out["0"][0], err_msg=f"{name} chunks {mode}")
+            np.testing.assert_array_equal(out[mode][1], out["0"][1], err_msg=f"{name} chunks {mode}")
+        assert out["0"][1][..., :3].max() > 0
