@@ -125,6 +125,7 @@ struct vrt_hip_ctx {
                                   // 13th starts when the first retires); VRT_HIP_RENDER_WAVES overrides
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
     int lists_for_shard = -1; // sharding mode the cell lists were built for
+    bool prep_pending = false; // the per-origin table (gA) of gA_origin is still to be written: by the next list kernel, or by flush_prep()
     bool lists_fresh = false; // the queue counters were zeroed by the list build of this very call
     uint32_t list_gen = 0;    // list generation: selects the counter set (see cell_grid)
     // dense-launch feedback (CellGrid::feedback): host-mapped, read frames later
@@ -287,13 +288,21 @@ int prep_frame(vrt_hip_ctx *c, const float origin[3], hipStream_t st)
         c->defer->do_prep = 1; c->defer->prep_gA = c->gA.p;
         memcpy(c->defer->prep_origin, origin, 3 * sizeof(float));
     } else {
-        launch_prep_frame(tables(c), c->gA.p, origin, st);
-        HIPCHK(c, hipGetLastError());
+        c->prep_pending = true; // the list kernel of this frame writes the table (BinArgs::prep_gA); flush_prep() launches it if none does
     }
     memcpy(c->gA_origin, origin, 3 * sizeof(float));
     c->cam_seq = c->frame_seq; // the camera moved
     c->gA_valid = true;
     c->lists_dirty = true; // the tile-level cull depends on the origin
+    return VRT_HIP_OK;
+}
+
+int flush_prep(vrt_hip_ctx *c, hipStream_t st)
+{
+    if (!c->prep_pending) return VRT_HIP_OK;
+    launch_prep_frame(tables(c), c->gA.p, c->gA_origin, st);
+    HIPCHK(c, hipGetLastError());
+    c->prep_pending = false;
     return VRT_HIP_OK;
 }
 
@@ -543,6 +552,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
             c->defer->bin = a; c->defer->fuse = f;
             c->deferred.lists = true; c->deferred.from_list = !device_bin; c->deferred.list_grid = n_local;
         } else if (n_local) {
+            if (c->prep_pending) { a.prep_gA = c->gA.p; c->prep_pending = false; } // a.R.origin is the origin prep_frame() noted
             launch_build_tile_lists(a, f, !device_bin, n_local, st);
         } else {
             // a rank that owns no tile (more ranks than tiles) launches no list kernel: nobody adds to this generation's
@@ -554,9 +564,13 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     } else {
         if (c->defer) return fail(c, VRT_HIP_ERR_INVALID, "frame batch: tiles of more than 64 cells (or rays that are no pinhole bundle) "
                                                           "need the two-kernel list path, which is not batched");
-        if (!c->work_is_ref) launch_build_tile_lists(a, f, !device_bin, (uint32_t)nt, st);
+        if (!c->work_is_ref) {
+            if (c->prep_pending) { a.prep_gA = c->gA.p; c->prep_pending = false; }
+            launch_build_tile_lists(a, f, !device_bin, (uint32_t)nt, st);
+        }
         else HIPCHK(c, hipMemsetAsync(c->c_counters.p + 8 * (c->list_gen & 1), 0, 8 * sizeof(uint32_t), st));
         HIPCHK(c, hipGetLastError());
+        if ((rc = flush_prep(c, st))) return rc; // the cell kernel reads the per-origin table: if no tile kernel wrote it, now
         launch_build_cell_lists(tables(c), work_lists(c), cell_grid(c), a.R, tile_map, c->n_cells, refine ? 1 : 0,
                                 (target && target->sparse) ? target->keys : nullptr, st);
         if (target && target->sparse) target->cleared = 1; // a sparse shard stores no empty cells: nothing to clear
@@ -685,6 +699,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     }
     if (c->retain_next && out_mode == OUT_RASTER && !use_shard && !c->defer) { o.stamp = c->own_stamp.p; o.stamp_seq = c->own_seq; }
     if ((rc = build_work_lists(c, origin, st, use_shard, &o))) return rc;
+    if ((rc = flush_prep(c, st))) return rc; // no list kernel took the per-origin table along (lists unchanged, caller-made lists used as they are, a batch)
     if (o.stamp && !o.cleared) c->own_seq = 0; // the list kernel of this frame was not the fused one: nobody kept the stamps
     const TileLists t = work_lists(c);
     if (o.stats) {

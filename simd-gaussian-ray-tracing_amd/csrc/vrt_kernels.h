@@ -174,6 +174,8 @@ struct Mat4 { float m[16]; };
 struct BinArgs {
     const float4 *mu_sig, *gA, *gB;
     uint32_t n;
+    float4 *prep_gA;                 // nullable: the list kernel also writes the per-origin table (centre - origin, squared norm) of ALL Gaussians for the
+                                     // kernels behind it -- what prep_frame_kernel does, without its launch; the list kernel itself works from mu_sig
     const float4 *chunks;            // nullable: bounding sphere (centre, radius incl. the members' reach) of every 64 consecutive Gaussians (launch_build_chunks)
     // input: caller-made lists (from_list) ...
     const uint32_t *in_start, *in_count, *in_indices;

@@ -2190,6 +2190,14 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     if (P.next_zero8 && lt == 0 && tid < 8) P.next_zero8[tid] = 0;
     unsigned long long *tl = (F.timeline && tid == 0) ? F.timeline + 8 * (size_t)lt : nullptr;
     if (tl) tl[0] = wall_clock64();
+    const float org_x = P.R.origin[0], org_y = P.R.origin[1], org_z = P.R.origin[2];
+    // the per-origin row of a Gaussian: centre - origin and its squared norm in vec4f_t::sqnorm order (types.h:69-72) -- prep_frame_kernel's arithmetic
+    auto rel = [&](const float4 &m) {
+        const float cx = m.x - org_x, cy = m.y - org_y, cz = m.z - org_z;
+        return make_float4(cx, cy, cz, dot3_ref(cx, cy, cz, cx, cy, cz));
+    };
+    if (P.prep_gA) // for the render kernels of this frame (this kernel reads none of it)
+        for (uint32_t i = blockIdx.x * 1024u + tid; i < P.n; i += gridDim.x * 1024u) P.prep_gA[i] = rel(P.mu_sig[i]);
 
     float x = 0.f, y = 0.f, ax = 0.f, ay = 0.f;
     uint32_t n_in;
@@ -2210,7 +2218,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     // (sub-pass u, wave, lane) lexicographic.
     bool keep[4];
     uint32_t idx[4];
-    float4 ga[4], gb[4], gm[4]; // gm: centre and sigma for the reference's tile test -- fetched with the other rows when the candidates are few (chunked)
+    float4 gb[4], gm[4]; // gm: centre and sigma -- the per-origin row is computed from it (rel), and the reference's tile test needs it anyway
     // chunked: the candidates are the members of the chunks that passed the chunk test, one chunk per (sub-pass, wave) -- the same
     // lexicographic (sub-pass, wave, lane) order as below, which is index order again
     bool chunked = !FROM_LIST && P.refine && P.chunks != nullptr;
@@ -2228,8 +2236,8 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
                 keep[u] = k < n_in;
                 idx[u] = keep[u] ? (FROM_LIST ? in_list[k] : k) : 0u;
             }
-            if (keep[u] && (P.refine || F.enabled)) { ga[u] = P.gA[idx[u]]; gb[u] = P.gB[idx[u]]; }
-            if (!FROM_LIST && chunked && keep[u]) gm[u] = P.mu_sig[idx[u]];
+            if (keep[u] && (P.refine || F.enabled)) gb[u] = P.gB[idx[u]];
+            if (keep[u] && (P.refine || F.enabled || !FROM_LIST)) gm[u] = P.mu_sig[idx[u]];
         }
     };
     if (!chunked) fetch(0); // in flight while the cone is set up
@@ -2284,12 +2292,12 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         for (int u = 0; u < 4; ++u) {
             // The result is (reference tile test) AND (cone test).  The cone test goes first: it is the cheaper
             // one (no divisions) and drops >95 % of the pairs in sparse scenes.
-            if (keep[u] && P.refine) keep[u] = cone_keeps(cone, ga[u], gb[u]);
+            if (keep[u] && P.refine) keep[u] = cone_keeps(cone, rel(gm[u]), gb[u]);
             if constexpr (!FROM_LIST) {
                 if (keep[u]) {
 #pragma clang fp contract(off)
                     keep[u] = false;
-                    const float4 g = chunked ? gm[u] : P.mu_sig[idx[u]];
+                    const float4 g = gm[u];
                     // glm mat4*vec4: (m0*v0 + m1*v1) + (m2*v2 + m3*v3), v = (mu, 1)   (rt.cpp:37)
                     const float vx = (P.V.m[0] * g.x + P.V.m[4] * g.y) + (P.V.m[8] * g.z + P.V.m[12] * 1.f);
                     const float vy = (P.V.m[1] * g.x + P.V.m[5] * g.y) + (P.V.m[9] * g.z + P.V.m[13] * 1.f);
@@ -2323,7 +2331,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
             if (keep[u]) {
                 const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[u], 0));
                 out[pos] = idx[u];
-                if (F.enabled && pos < TCAP) { s_idx[pos] = idx[u]; s_A[pos] = ga[u]; s_B[pos] = gb[u]; }
+                if (F.enabled && pos < TCAP) { s_idx[pos] = idx[u]; s_A[pos] = rel(gm[u]); s_B[pos] = gb[u]; }
             }
         }
         total += (uint32_t)__shfl((int)incl, 63, 64);
