@@ -313,7 +313,8 @@ int vrt_hip_set_table_budget(vrt_hip_ctx *ctx, float budget);
 /* Budgeted ray-level cull of the one-wave ("block") kernel.  `cull_eps` (vrt_hip_set_options; replaces nothing in the reference,
  * which sums every Gaussian of a tile: rt.h:205-223) bounds what dropped Gaussians can change by worst-case counting; a ray's own
  * list is additionally cut by the SUM of what it drops: the smallest entries go while sum sigma*mag*exp(-x) <= kappa * 1365 * cull_eps
- * (default kappa 6: the ray's radiance changes by at most 3 * that = 2.46e-5; 0 = off; cull_eps = 0 switches every cull off). */
+ * (default kappa 6: the ray's radiance changes by at most 3 * that = 2.46e-5 for albedos <= 1 -- the budget is divided by the scene's
+ * largest albedo beyond that; 0 = off; cull_eps = 0 switches every cull off). */
 int vrt_hip_set_cull_prune(vrt_hip_ctx *ctx, float kappa);
 
 /* -------- statistics of the last render ----------------------------------------------------- */

@@ -114,6 +114,7 @@ struct vrt_hip_ctx {
                                  // lanes where an instruction-count model says they are cheaper; 2: wherever they fit.  Measured: -10 % VALU
                                  // instructions, -1 % time (profiles/r03_experiments.md): off
     bool skip_idle_dense = true; // VRT_HIP_DENSE_SKIP=0: the dense kernel is launched behind every block kernel
+    float albedo_scale = 1.f;    // max(1, largest |albedo| of the scene): divides the prune budget
     float cull_prune = 6.f;      // vrt_hip_set_cull_prune(): a block-kernel ray may drop the smallest entries of its list while their sum stays below
                                  // cull_prune * cull_ref_n * cull_eps (prune_list; 0 = off).  6: 3 * 6 * 1365 * 1e-9 = 2.46e-5 -- DESIGN.md section 4
     float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
@@ -433,7 +434,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.table_room = c->table_room; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
     g.pair_lanes = c->pair_lanes;
     // prune_list sums sigma*mag*exp(-x) in units of the TILE level's eps (cull_x = ln(sigma*mag / eps_eff), rebuild_tables)
-    g.prune_budget = (c->cull_eps > 0.f) ? c->cull_prune * (c->cull_ref_n > 0.f ? c->cull_ref_n : 4096.f / 3.f) * std::max(1.f, (float)c->n / 4096.f) : 0.f;
+    g.prune_budget = (c->cull_eps > 0.f) ? c->cull_prune * (c->cull_ref_n > 0.f ? c->cull_ref_n : 4096.f / 3.f) * std::max(1.f, (float)c->n / 4096.f) / c->albedo_scale : 0.f;
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
     g.feedback = c->d_fb;
     g.dense_is_sorted = 1;
@@ -964,6 +965,11 @@ int vrt_hip_set_gaussians(vrt_hip_ctx *c, size_t n, const float *mu_x, const flo
         if (n && src[i]) HIPCHK(c, hipMemcpy(c->soa[i].p, src[i], n * sizeof(float), hipMemcpyHostToDevice));
     }
     c->has_alpha = aa != nullptr;
+    // the cull bounds count a dropped Gaussian's emission at albedo <= 1 (the reference's range): brighter scenes shrink the prune's budget
+    c->albedo_scale = 1.f;
+    for (int ch = 3; ch <= 6; ++ch)
+        if (src[ch])
+            for (size_t i = 0; i < n; ++i) { const float v = fabsf(src[ch][i]); if (v > c->albedo_scale && v < INFINITY) c->albedo_scale = v; }
     c->n = (uint32_t)n;
     ++c->state_gen;
     c->reset_seq = c->frame_seq;
@@ -1018,7 +1024,7 @@ int vrt_hip_copy_state(vrt_hip_ctx *dst, const vrt_hip_ctx *src)
         HIPCHK(dst, dst->soa[i].reserve(src->n));
         if (src->n && src->soa[i].p) HIPCHK(dst, hipMemcpy(dst->soa[i].p, src->soa[i].p, (size_t)src->n * sizeof(float), hipMemcpyDeviceToDevice));
     }
-    dst->has_alpha = src->has_alpha; dst->n = src->n;
+    dst->has_alpha = src->has_alpha; dst->n = src->n; dst->albedo_scale = src->albedo_scale;
     dst->exp_kind = src->exp_kind; dst->erf_kind = src->erf_kind; dst->cull_eps = src->cull_eps; dst->cull_prune = src->cull_prune;
     dst->table_hx = src->table_hx; dst->table_budget = src->table_budget; dst->table_adapt = src->table_adapt; dst->table_room = src->table_room;
     dst->rank = src->rank; dst->world = src->world;
