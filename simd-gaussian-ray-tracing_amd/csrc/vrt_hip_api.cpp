@@ -1591,7 +1591,7 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
     HIPCHK(c0, hipEventRecord(c0->batch_copied[slot], st));
     launch_frame_setup_batch(d_rows, rows, (uint32_t)n, st); // per-origin tables and cone tables of the frames that need new ones
     const auto &d0 = c0->deferred;
-    if (d0.lists) launch_build_tile_lists_batch(d_rows, (uint32_t)n, d0.from_list, d0.list_grid, st);
+    if (d0.lists) launch_build_tile_lists_batch(d_rows, (uint32_t)n, d0.from_list, !d0.from_list && rows[0].bin.chunks && rows[0].bin.refine, d0.list_grid, st); // (same scene size and geometry in every frame: checked above)
     // one-wave kernel: the persistent grid of ONE frame fills the GPU; n frames share it (at least one workgroup each --
     // a workgroup pulls the blocks beyond its first from the frame's queues)
     static const uint32_t oversub = [] { const char *e = getenv("VRT_HIP_BATCH_OVERSUB"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();

@@ -227,7 +227,7 @@ struct FrameArgs {
     int do_cones; uint32_t cones_tiles, cones_cx, cones_cy; float4 *cones_out; // tile_cones_kernel for this frame's camera (bin = its rays and tile geometry)
     int do_order;                                                 // order_dense_kernel
 };
-void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, uint32_t ntiles, hipStream_t st);
+void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, bool chunks, uint32_t ntiles, hipStream_t st);
 void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
 void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int dw, int exp_kind, int erf_kind,
                                hipStream_t st);

@@ -2172,15 +2172,16 @@ __device__ __forceinline__ bool chunk_keeps(const Cone &k, float4 ch, float ox, 
     return !(dmin * 0.9999f > ch.w);
 }
 
-template <bool FROM_LIST>
+template <bool FROM_LIST, bool CHUNKS>
 __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const FuseArgs &F)
 {
+    static_assert(!(FROM_LIST && CHUNKS), "chunks are runs of consecutive indices: device binning only");
     __shared__ uint32_t s_wave_cnt[64];
     __shared__ uint32_t s_idx[TCAP];
     __shared__ float4 s_A[TCAP], s_B[TCAP];
     __shared__ uint32_t s_flag[MAX_FUSED_CELLS], s_inact[MAX_FUSED_CELLS];
     __shared__ uint32_t s_base[4];
-    __shared__ uint32_t s_chunk[FROM_LIST ? 1 : CH_CAP];
+    __shared__ uint32_t s_chunk[CHUNKS ? CH_CAP : 1];
     const uint32_t lt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t t = F.tile_map ? F.tile_map[lt] : lt;
     const uint32_t tx = t % P.tiles_w, ty = t / P.tiles_w;
@@ -2196,8 +2197,6 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         const float cx = m.x - org_x, cy = m.y - org_y, cz = m.z - org_z;
         return make_float4(cx, cy, cz, dot3_ref(cx, cy, cz, cx, cy, cz));
     };
-    if (P.prep_gA) // for the render kernels of this frame (this kernel reads none of it)
-        for (uint32_t i = blockIdx.x * 1024u + tid; i < P.n; i += gridDim.x * 1024u) P.prep_gA[i] = rel(P.mu_sig[i]);
 
     float x = 0.f, y = 0.f, ax = 0.f, ay = 0.f;
     uint32_t n_in;
@@ -2221,12 +2220,12 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     float4 gb[4], gm[4]; // gm: centre and sigma -- the per-origin row is computed from it (rel), and the reference's tile test needs it anyway
     // chunked: the candidates are the members of the chunks that passed the chunk test, one chunk per (sub-pass, wave) -- the same
     // lexicographic (sub-pass, wave, lane) order as below, which is index order again
-    bool chunked = !FROM_LIST && P.refine && P.chunks != nullptr;
+    bool chunked = CHUNKS && P.refine && P.chunks != nullptr;
     uint32_t n_slots = 0;
     auto fetch = [&](uint32_t base) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (!FROM_LIST && chunked) {
+            if (CHUNKS && chunked) {
                 const uint32_t slot = base / 64u + u * 16u + wave;
                 idx[u] = slot < n_slots ? s_chunk[slot] * 64u + lane : 0xFFFFFFFFu;
                 keep[u] = idx[u] < n_in;
@@ -2240,7 +2239,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
             if (keep[u] && (P.refine || F.enabled || !FROM_LIST)) gm[u] = P.mu_sig[idx[u]];
         }
     };
-    if (!chunked) fetch(0); // in flight while the cone is set up
+    if (!CHUNKS || !chunked) fetch(0); // in flight while the cone is set up
     // (b) tile cone from the centre and the four corner pixels of the tile (pinhole rays: the
     // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
     Cone cone = {};
@@ -2254,7 +2253,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         }
     }
 
-    if constexpr (!FROM_LIST) {
+    if constexpr (CHUNKS) {
         if (chunked) { // ---- chunk test: one sphere per thread and pass, order-preserving compaction of the chunk ids ----
             const uint32_t nch = (n_in + 63u) / 64u;
             const float ox = P.R.origin[0], oy = P.R.origin[1], oz = P.R.origin[2];
@@ -2284,7 +2283,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         }
     }
     if (tl) tl[1] = wall_clock64();
-    const uint32_t n_cand = (!FROM_LIST && chunked) ? n_slots * 64u : n_in;
+    const uint32_t n_cand = (CHUNKS && chunked) ? n_slots * 64u : n_in;
     for (uint32_t base = 0; base < n_cand; base += 4096) {
         if (base) fetch(base);
         unsigned long long mask[4];
@@ -2340,7 +2339,12 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     const float slack = level_slack(P.cull_ref_n, total); // cell level: the tile's work list enters
     if (tid == 0) P.out_count[t] = total;
     if (tl) tl[2] = wall_clock64();
-    if (!F.enabled) return;
+    // the per-origin table for the render kernels of this frame (this kernel reads none of it): behind everything the frame waits for
+    auto write_prep = [&]() {
+        if (P.prep_gA)
+            for (uint32_t i = blockIdx.x * 1024u + tid; i < P.n; i += gridDim.x * 1024u) P.prep_gA[i] = rel(P.mu_sig[i]);
+    };
+    if (!F.enabled) { write_prep(); return; }
 
     // ---------------- second level, fused ----------------
     const CellGrid &C = F.C;
@@ -2432,7 +2436,7 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     // ---- clear the cells nothing can reach: 4 B per ray, most of the frame's HBM traffic.  All 1024 threads,
     //      16-byte stores (4 pixels per lane, 512 B per row segment) when the geometry is 4-pixel aligned ----
     if (tl) tl[4] = wall_clock64();
-    if (!F.do_clear) return;
+    if (!F.do_clear) { write_prep(); return; }
     const uint32_t zero_px = (F.O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
     const bool wide = F.O.image && !F.O.radiance && (P.tile_w % 4 == 0) && (P.stride % 4 == 0) &&
                       ((uintptr_t)F.O.image % 16 == 0) && (!F.O.compact || (P.tile_w * P.tile_h) % 4 == 0);
@@ -2460,29 +2464,32 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         }
     }
     if (tl) tl[5] = wall_clock64();
+    write_prep();
 }
-template <bool FROM_LIST>
+template <bool FROM_LIST, bool CHUNKS = false>
 __global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseArgs F)
 {
-    build_tile_lists_body<FROM_LIST>(P, F);
+    build_tile_lists_body<FROM_LIST, CHUNKS>(P, F);
 }
-template <bool FROM_LIST>
+template <bool FROM_LIST, bool CHUNKS = false>
 __global__ __launch_bounds__(1024) void build_tile_lists_batch_kernel(const FrameArgs *__restrict__ frames)
 {
     const FrameArgs &a = frames[blockIdx.y];
-    build_tile_lists_body<FROM_LIST>(a.bin, a.fuse);
+    build_tile_lists_body<FROM_LIST, CHUNKS>(a.bin, a.fuse);
 }
 
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st)
 {
     if (!ntiles) return;
     if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, a, f);
+    else if (a.chunks && a.refine) hipLaunchKernelGGL((build_tile_lists_kernel<false, true>), dim3(ntiles), dim3(1024), 0, st, a, f);
     else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, a, f);
 }
-void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, uint32_t ntiles, hipStream_t st)
+void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, bool chunks, uint32_t ntiles, hipStream_t st)
 {
     if (!ntiles || !nframes) return;
     if (from_list) hipLaunchKernelGGL(build_tile_lists_batch_kernel<true>, dim3(ntiles, nframes), dim3(1024), 0, st, d_frames);
+    else if (chunks) hipLaunchKernelGGL((build_tile_lists_batch_kernel<false, true>), dim3(ntiles, nframes), dim3(1024), 0, st, d_frames);
     else hipLaunchKernelGGL(build_tile_lists_batch_kernel<false>, dim3(ntiles, nframes), dim3(1024), 0, st, d_frames);
 }
 
