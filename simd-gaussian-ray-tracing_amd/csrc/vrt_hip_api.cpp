@@ -110,6 +110,7 @@ struct vrt_hip_ctx {
     // cells with at most this many candidates are shaded last (CellGrid::light_threshold; VRT_HIP_LIGHT_CELLS, 0 = off);
     // lists_light: what the lists now in the buffers were built with (0 for sparse shards and the two-kernel list path)
     uint32_t light_cells = 24, lists_light = 0;
+    int claim_early = 8;         // CellGrid::claim_early (measured: 2 leaves `-g 16 -w 2048` at 67 us, 8 takes it to 43, "always" costs a 12-waves-per-CU grid 8 % in flight); VRT_HIP_CLAIM_EARLY=0: the block kernel's waves ask for their next block only when they are done with the current one
     int pair_lanes = 0;          // VRT_HIP_PAIR_LANES: 0 (default) the block kernel shades every block ray per lane; 1: (ray, emitter) pairs as
                                  // lanes where an instruction-count model says they are cheaper; 2: wherever they fit.  Measured: -10 % VALU
                                  // instructions, -1 % time (profiles/r03_experiments.md): off
@@ -433,6 +434,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
     g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.table_room = c->table_room; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
     g.pair_lanes = c->pair_lanes;
+    g.claim_early = c->claim_early;
     // prune_list sums sigma*mag*exp(-x) in units of the TILE level's eps (cull_x = ln(sigma*mag / eps_eff), rebuild_tables)
     g.prune_budget = (c->cull_eps > 0.f) ? c->cull_prune * (c->cull_ref_n > 0.f ? c->cull_ref_n : 4096.f / 3.f) * std::max(1.f, (float)c->n / 4096.f) / c->albedo_scale : 0.f;
     g.dense_threshold = 96; // longer cell lists go straight to the 16-waves-per-block kernel (must be <= PCAP)
@@ -898,6 +900,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     if (const char *e = getenv("VRT_HIP_TABLE_BUDGET")) { const float v = (float)atof(e); if (v > 0.f) c->table_budget = v; }
     if (const char *e = getenv("VRT_HIP_TILE_CONES")) c->cache_cones = atoi(e) != 0;
     if (const char *e = getenv("VRT_HIP_LIGHT_CELLS")) c->light_cells = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("VRT_HIP_CLAIM_EARLY")) c->claim_early = std::max(0, atoi(e));
     if (const char *e = getenv("VRT_HIP_PAIR_LANES")) c->pair_lanes = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("VRT_HIP_DENSE_SKIP")) c->skip_idle_dense = atoi(e) != 0;
     if (const char *e = getenv("VRT_HIP_DENSE_IDLE_GRID")) {

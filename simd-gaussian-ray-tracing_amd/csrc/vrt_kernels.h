@@ -81,6 +81,8 @@ struct CellGrid {
                                      // LDS slots: it hands them to the dense kernel, which runs after it
     uint32_t dense_threshold;        // a cell whose list is longer than this goes to the dense queue
     float prune_budget;              // block kernel: a ray may drop the smallest entries of its list while their sum (units of the tile level's eps) stays below this (prune_list; 0 = off)
+    int claim_early;                 // block kernel: a wave claims its next queue entry before it shades the current block when the queues hold at least
+                                     // 1/claim_early of the grid size in entries (VRT_HIP_CLAIM_EARLY; 0: never -- after the block, as in rounds 1-2)
     int pair_lanes;                  // block kernel: blocks with short per-ray lists are shaded with (ray, emitter) pairs as lanes (shade_pairs)
     // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame (written by the one-wave kernel),
     // [2] = items (blocks) the dense kernel found in its queues, [3] = sequence number of the frame that wrote [2]
@@ -103,7 +105,10 @@ struct CellGrid {
                                      // of the error bound leaves room (1 = always as requested)
     uint32_t *overflow2, *n_overflow2;
 };
-constexpr uint32_t RQ_N = 8, RQ_STRIDE = 64;
+#ifndef VRT_RQ_N
+#define VRT_RQ_N 64
+#endif
+constexpr uint32_t RQ_N = VRT_RQ_N, RQ_STRIDE = 64; // RQ_N <= 64: a wave looks at all counters at once, one per lane
 
 struct RayGen {
     const float *xs, *ys, *zs; // plane arrays (nullptr => basis mode)

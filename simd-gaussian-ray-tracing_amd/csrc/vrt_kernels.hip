@@ -781,7 +781,26 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             if (O.radiance) O.radiance[out] = make_float4(Lr, Lg, Lb, La);
         }
     };
-    for (uint32_t item = wave; item < n_shade; item = next_item()) {
+    // The next entry of the wave's own queue is claimed BEFORE the block is shaded: the atomic's round trip (device scope: microseconds
+    // when thousands of waves ask) passes behind the pair loops instead of in front of the next block's chain of loads.  A claimed entry
+    // is always worked off by the wave that claimed it.  (Issued after the cull's loads have been consumed: returns are in order.)
+    const uint32_t q_own = wave % RQ_N, per_own = n_dyn > q_own ? (n_dyn - q_own + RQ_N - 1) / RQ_N : 0u;
+    // (only where most claims succeed: with few entries beyond the static ones thousands of failing claims would queue up on 8 counters)
+    const bool claim_early = C.claim_early > 0 && per_own && (uint64_t)n_dyn * (uint32_t)C.claim_early >= G;
+    uint32_t claim = 0xFFFFFFFFu;
+    bool claimed = false;
+    auto advance = [&]() -> uint32_t {
+        if constexpr (NW == 1) {
+            if (claimed) {
+                claimed = false;
+                const uint32_t m = __builtin_amdgcn_readfirstlane(claim);
+                if (m < per_own) return G + q_own + RQ_N * m;
+                rq_dead |= 1u; // the own queue is empty for good
+            }
+        }
+        return next_item();
+    };
+    for (uint32_t item = wave; item < n_shade; item = advance()) {
         const unsigned long long tl0 = O.timeline ? wall_clock64() : 0ull; // diagnostics (VRT_HIP_TIMELINE runs only)
         const uint32_t ci = item >> 4;
         const uint32_t entry = (item == wave && ci < n_active) ? spec_entry : C.active[ci < n_active ? ci : C.n_cells - 1u - (ci - n_active)];
@@ -920,6 +939,12 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); atomicAdd(&O.stats[12], sq); }
         }
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
+        if constexpr (NW == 1) {
+            if (claim_early && !(rq_dead & 1u)) {
+                claimed = true;
+                if (first) claim = atomicAdd(C.rq + q_own * RQ_STRIDE, 1u);
+            }
+        }
         float Lr, Lg, Lb, La;
         if constexpr (NW == 1) {
 #ifdef VRT_PAIR_LANES // experiment (profiles/r03_experiments.md): make LANES='-DVRT_RENDER_ECMAX=6 -DVRT_RENDER_WPE=3 -DVRT_PAIR_LANES', VRT_HIP_PAIR_LANES=1|2
