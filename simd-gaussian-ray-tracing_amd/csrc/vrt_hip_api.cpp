@@ -751,6 +751,13 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     }
     if (no_dense_work) ++c->last.dense_launch_skips;
     CellGrid cg = cell_grid(c);
+    // the block kernel's variant that claims its next queue entry early: for frames with (by an earlier frame's report, however old:
+    // speed only) at least grid / claim_early more blocks than the grid has waves
+    {
+        const uint32_t seen_blocks = (c->h_fb && !c->stats_on) ? c->h_fb[1] : 0u;
+        const bool many = c->claim_early > 0 && seen_blocks > grid && (uint64_t)(seen_blocks - grid) * (uint32_t)c->claim_early >= grid;
+        cg.claim_early = many ? c->claim_early : 0;
+    }
     cg.dense_is_sorted = expect_dense ? 1 : 0;
     cg.frame_seq = ++c->frame_seq;
     if (!c->c_rq.p) {
@@ -1590,16 +1597,25 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
         return failed;
     }
     for (int i = 0; i < n; ++i) rows[i].do_order = ctxs[i]->deferred.order ? 1 : 0;
+    // one-wave kernel: the persistent grid of ONE frame fills the GPU; n frames share it -- so a frame of a batch has 1/n of the waves and
+    // that many more queue entries: the variant that claims them early is chosen against the per-frame grid
+    static const uint32_t oversub = [] { const char *e = getenv("VRT_HIP_BATCH_OVERSUB"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
+    const uint32_t full_grid = c0->deferred.render_grid;
+    const uint32_t rgrid = full_grid ? std::min(full_grid, std::max(1u, (full_grid * oversub + (uint32_t)n - 1) / (uint32_t)n)) : 0u;
+    bool claim = false;
+    for (int i = 0; i < n; ++i) {
+        const vrt_hip_ctx *c = ctxs[i];
+        const uint32_t seen_blocks = (c->h_fb && !c->stats_on) ? c->h_fb[1] : 0u;
+        const bool many = c->claim_early > 0 && seen_blocks > rgrid && (uint64_t)(seen_blocks - rgrid) * (uint32_t)c->claim_early >= rgrid;
+        rows[i].C.claim_early = many ? c->claim_early : 0;
+        claim = claim || many;
+    }
     HIPCHK(c0, hipMemcpyAsync(d_rows, rows, (size_t)n * sizeof(FrameArgs), hipMemcpyHostToDevice, st));
     HIPCHK(c0, hipEventRecord(c0->batch_copied[slot], st));
     launch_frame_setup_batch(d_rows, rows, (uint32_t)n, st); // per-origin tables and cone tables of the frames that need new ones
     const auto &d0 = c0->deferred;
     if (d0.lists) launch_build_tile_lists_batch(d_rows, (uint32_t)n, d0.from_list, !d0.from_list && rows[0].bin.chunks && rows[0].bin.refine, d0.list_grid, st); // (same scene size and geometry in every frame: checked above)
-    // one-wave kernel: the persistent grid of ONE frame fills the GPU; n frames share it (at least one workgroup each --
-    // a workgroup pulls the blocks beyond its first from the frame's queues)
-    static const uint32_t oversub = [] { const char *e = getenv("VRT_HIP_BATCH_OVERSUB"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
-    const uint32_t rgrid = d0.render_grid ? std::min(d0.render_grid, std::max(1u, (d0.render_grid * oversub + (uint32_t)n - 1) / (uint32_t)n)) : 0u;
-    launch_render_batch(d_rows, (uint32_t)n, rgrid, c0->exp_kind, c0->erf_kind, st);
+    launch_render_batch(d_rows, (uint32_t)n, rgrid, claim, c0->exp_kind, c0->erf_kind, st);
     uint32_t dgrid = 0;
     for (int i = 0; i < n; ++i) dgrid = std::max(dgrid, ctxs[i]->deferred.dense_grid);
     launch_order_dense_batch(d_rows, rows, (uint32_t)n, st);

@@ -84,9 +84,9 @@ struct CellGrid {
     int claim_early;                 // block kernel: a wave claims its next queue entry before it shades the current block when the queues hold at least
                                      // 1/claim_early of the grid size in entries (VRT_HIP_CLAIM_EARLY; 0: never -- after the block, as in rounds 1-2)
     int pair_lanes;                  // block kernel: blocks with short per-ray lists are shaded with (ray, emitter) pairs as lanes (shade_pairs)
-    // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame (written by the one-wave kernel),
+    // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame, [1] = blocks of its active cells (written by the one-wave kernel),
     // [2] = items (blocks) the dense kernel found in its queues, [3] = sequence number of the frame that wrote [2]
-    // ([1] unused).  The host reads it frames later to SIZE the dense launch: a frame that is expected to have nothing
+    // The host reads it frames later to SIZE the dense launch: a frame that is expected to have nothing
     // for it gets a handful of workgroups instead of one per CU and no queue sort.  Which kernel shades a block never
     // depends on it.
     uint32_t *feedback;
@@ -233,7 +233,7 @@ struct FrameArgs {
     int do_order;                                                 // order_dense_kernel
 };
 void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, bool chunks, uint32_t ntiles, hipStream_t st);
-void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
+void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, bool claim, int exp_kind, int erf_kind, hipStream_t st);
 void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int dw, int exp_kind, int erf_kind,
                                hipStream_t st);
 // the per-frame set-up kernels of a batch, one launch each: prep_frame (grid.y = frame), tile_cones, order_dense

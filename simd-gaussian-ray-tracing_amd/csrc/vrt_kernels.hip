@@ -675,7 +675,7 @@ __device__ __forceinline__ uint32_t prune_list(const __half *s_t, uint8_t *s_lan
 // three resident waves each: with whole blocks as the unit half of the SIMDs carry three heavy blocks and the rest two
 // (27 us against a balanced 21 us, VRT_HIP_TIMELINE); with half blocks pulled from the work queues the unit is half
 // as long and the per-SIMD sums even out.
-template <int EXP, int ERF, int EC, int NW>
+template <int EXP, int ERF, int EC, int NW, bool CLAIM = false>
 __device__ __forceinline__ void render_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R, const RenderTarget &O)
 {
     // every row a kept candidate needs later (absorber: A, B; emitter: mu/sigma, albedo, sigma*mag) is fetched in the one
@@ -703,6 +703,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     }
     const uint32_t n_light = C.light_threshold ? *C.n_light : 0u; // cells filed from the back of the queue: shaded last
     const uint32_t n_shade = (n_active + n_light) * 16u; // the dense cells belong to the 16-waves-per-block kernel behind this one
+    if (C.feedback && wave == 0 && first) __hip_atomic_store(&C.feedback[1], n_shade, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // for the host's choice of the CLAIM variant
     if (O.sparse_hdr && wave == 0 && first) { // sparse shard header; the counts are final: the list kernel is done
         O.sparse_hdr[0] = n_active + n_dense_cells; O.sparse_hdr[1] = O.sparse_cap;
         O.sparse_hdr[2] = C.cells_x * C.cells_y; O.sparse_hdr[3] = 0;
@@ -786,11 +787,13 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     // is always worked off by the wave that claimed it.  (Issued after the cull's loads have been consumed: returns are in order.)
     const uint32_t q_own = wave % RQ_N, per_own = n_dyn > q_own ? (n_dyn - q_own + RQ_N - 1) / RQ_N : 0u;
     // (only where most claims succeed: with few entries beyond the static ones thousands of failing claims would queue up on 8 counters)
-    const bool claim_early = C.claim_early > 0 && per_own && (uint64_t)n_dyn * (uint32_t)C.claim_early >= G;
+    // (a kernel variant of its own, CLAIM: with the claim compiled in, the kernel that never claims -- the headline frame has no queue entry
+    // at all -- ran 6 % longer: 10 more VGPRs, 20 more spilled SGPRs; the host picks the variant from what earlier frames reported)
+    const bool claim_early = CLAIM && C.claim_early > 0 && per_own && (uint64_t)n_dyn * (uint32_t)C.claim_early >= G;
     uint32_t claim = 0xFFFFFFFFu;
     bool claimed = false;
     auto advance = [&]() -> uint32_t {
-        if constexpr (NW == 1) {
+        if constexpr (NW == 1 && CLAIM) {
             if (claimed) {
                 claimed = false;
                 const uint32_t m = __builtin_amdgcn_readfirstlane(claim);
@@ -939,7 +942,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); atomicAdd(&O.stats[12], sq); }
         }
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
-        if constexpr (NW == 1) {
+        if constexpr (NW == 1 && CLAIM) {
             if (claim_early && !(rq_dead & 1u)) {
                 claimed = true;
                 if (first) claim = atomicAdd(C.rq + q_own * RQ_STRIDE, 1u);
@@ -1000,17 +1003,17 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     }
 }
 
-template <int EXP, int ERF, int EC, int NW>
+template <int EXP, int ERF, int EC, int NW, bool CLAIM = false>
 __global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
 {
-    render_body<EXP, ERF, EC, NW>(S, T, C, R, O);
+    render_body<EXP, ERF, EC, NW, CLAIM>(S, T, C, R, O);
 }
 // several frames per launch: blockIdx.y is the frame (FrameArgs)
-template <int EXP, int ERF, int EC>
+template <int EXP, int ERF, int EC, bool CLAIM = false>
 __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_batch_kernel(const FrameArgs *__restrict__ frames)
 {
     const FrameArgs &a = frames[blockIdx.y];
-    render_body<EXP, ERF, EC, 1>(a.S, a.T, a.C, a.R, a.O);
+    render_body<EXP, ERF, EC, 1, CLAIM>(a.S, a.T, a.C, a.R, a.O);
 }
 
 // This file is compiled twice (csrc/Makefile): once for everything except the one-wave image kernel, and once with
@@ -1886,14 +1889,17 @@ static void launch_render_t(const SceneTables &s, const TileLists &t, const Cell
 {
     if (grid == 0) return;
     if (nw == 2) hipLaunchKernelGGL((render_kernel<EXP, ERF, 4, 2>), dim3(grid), dim3(128), 0, st, s, t, c, r, o);
+    else if (c.claim_early > 0 && EXP == VRT_EXP_VCL && ERF == VRT_ERF_AS) // frames with many more blocks than waves (the default pair only: compile time)
+        hipLaunchKernelGGL((render_kernel<VRT_EXP_VCL, VRT_ERF_AS, 4, 1, true>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
     else hipLaunchKernelGGL((render_kernel<EXP, ERF, 4, 1>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
 }
 
 template <int EXP, int ERF>
-static void launch_render_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, hipStream_t st)
+static void launch_render_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, bool claim, hipStream_t st)
 {
     if (grid == 0 || nframes == 0) return;
-    hipLaunchKernelGGL((render_batch_kernel<EXP, ERF, 4>), dim3(grid, nframes), dim3(64), 0, st, d_frames);
+    if (claim && EXP == VRT_EXP_VCL && ERF == VRT_ERF_AS) hipLaunchKernelGGL((render_batch_kernel<VRT_EXP_VCL, VRT_ERF_AS, 4, true>), dim3(grid, nframes), dim3(64), 0, st, d_frames);
+    else hipLaunchKernelGGL((render_batch_kernel<EXP, ERF, 4>), dim3(grid, nframes), dim3(64), 0, st, d_frames);
 }
 
 #endif // VRT_TU_LANES
@@ -1918,9 +1924,9 @@ void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, 
 {
     VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, nw, st);
 }
-void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, bool claim, int exp_kind, int erf_kind, hipStream_t st)
 {
-    VRT_DISPATCH_EXP_ERF(launch_render_batch_t, d_frames, nframes, grid, st);
+    VRT_DISPATCH_EXP_ERF(launch_render_batch_t, d_frames, nframes, grid, claim, st);
 }
 #elif defined(VRT_TU_TABLE)
 // The table kernel's error bound is that of the Abramowitz-Stegun erf (its kink) or of a smoother one (libm); the Exp must

@@ -1024,3 +1024,42 @@ def test_chunked_tile_level_gives_the_same_lists(pkg, oracle, monkeypatch):
             np.testing.assert_array_equal(out[mode][0], out["0"][0], err_msg=f"{name} chunks {mode}")
             np.testing.assert_array_equal(out[mode][1], out["0"][1], err_msg=f"{name} chunks {mode}")
         assert out["0"][1][..., :3].max() > 0
+
+
+def test_frames_with_more_blocks_than_waves(pkg, oracle, monkeypatch):
+    """Frames whose blocks outnumber the block kernel's resident waves are worked off through the work queues; since round 3 a wave
+    claims its next entry before it shades the current block (VRT_HIP_CLAIM_EARLY, default from 1/8 of the grid size in entries;
+    a kernel variant of its own, chosen from what the previous frame reported).
+    Which wave shades a block must not matter: the frame equals the one of the old order (claim after the block) bit for bit, with
+    the default grid and with a small one (VRT_HIP_RENDER_WAVES=3: every wave walks through a dozen blocks), and the oracle's pixels."""
+    from sgrt_amd import scene
+    g = scene.grid_scene(16)
+    w = 3072
+    cam, _ = scene.cli_camera(w, w, initial_rot=12.0)
+    frames = {}
+    for claim, waves in (("0", "13"), ("8", "13"), ("1000000", "3"), ("8", "5")):
+        monkeypatch.setenv("VRT_HIP_CLAIM_EARLY", claim)
+        monkeypatch.setenv("VRT_HIP_RENDER_WAVES", waves)
+        r = pkg.Renderer(0)
+        try:
+            r.set_gaussians(g); r.set_camera_view(w, w, cam.view); r.tile_gaussians(2 / 16, 2 / 16, cam.view)
+            first = r.render(cam.position)      # reports its block count; the kernel variant of the NEXT frame follows the report
+            img, rad = r.render(cam.position)
+            np.testing.assert_array_equal(first[0], img); np.testing.assert_array_equal(first[1], rad)
+            r.enable_stats(True)
+            r.render(cam.position, want_radiance=False)
+            assert r.stats()["shaded_blocks"] > 2 * 13 * 256
+            frames[(claim, waves)] = (img, rad)
+        finally:
+            r.close()
+    ref = frames[("0", "13")]
+    for k, (img, rad) in frames.items():
+        np.testing.assert_array_equal(img, ref[0], err_msg=str(k))
+        np.testing.assert_array_equal(rad, ref[1], err_msg=str(k))
+    lum = ref[1][..., :3].sum(-1).reshape(-1)
+    pix = np.random.default_rng(5).choice(np.flatnonzero(lum > 0.25 * lum.max()), 96, replace=False).astype(np.uint32)
+    ocam, _ = oracle.cli_camera(w, w, initial_rot=12.0)
+    view = oracle.camera_view(ocam)
+    tiles = oracle.tile_gaussians(2 / 16, 2 / 16, g.view(oracle.GAUSSIAN), view)
+    orad = oracle.render(w, w, oracle.camera_plane(ocam), ocam.position[:], g.view(oracle.GAUSSIAN), tiles, pixels=pix, want_image=False)[1]
+    assert np.abs(ref[1].reshape(-1, 4)[pix] - orad).max() <= TOL
