@@ -104,6 +104,7 @@ struct vrt_hip_ctx {
     // tile cones of the list kernel: a function of the rays and the tile geometry only, kept across frames (cone_key =
     // what they were made for; VRT_HIP_TILE_CONES=0: every workgroup builds its own, as before)
     DevBuf<float4> tile_cones;
+    uint32_t cone_gen = 0;     // tag of the rows made for cone_key's camera (BinArgs::cone_gen)
     std::string cone_key;
     uint32_t plane_gen = 0;
     bool cache_cones = true;
@@ -506,18 +507,28 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         const uint32_t cpt = c->cells_x * c->cells_y;
         const uint32_t cones_cells = cpt <= (uint32_t)MAX_FUSED_CELLS ? cpt : 0u;
         const size_t rows = nt * (1 + cones_cells);
-        if (key != c->cone_key || c->tile_cones.cap < 2 * rows) {
+        // The table fills itself: a row is valid if it carries the tag of this camera (cone_gen); the list kernel's workgroups build the cones
+        // they do not find and file them (round 3: the table's own launch cost a frame whose camera moved 5 us).  Frames of a batch get
+        // theirs from one launch for the whole batch, as before.
+        bool known = true;
+        if (c->tile_cones.cap < 2 * rows) {
             HIPCHK(c, c->tile_cones.reserve(2 * rows));
+            HIPCHK(c, hipMemsetAsync(c->tile_cones.p, 0, c->tile_cones.cap * sizeof(float4), st)); // tag 0: no camera's
+            c->cone_key.clear();
+        }
+        if (key != c->cone_key) {
+            if (++c->cone_gen == 0u) c->cone_gen = 1u;
+            a.cone_gen = c->cone_gen;
+            known = false;
             if (c->defer) { // a frame of a batch: one cone launch for all frames (its BinArgs are the frame's bin row)
                 c->defer->do_cones = 1; c->defer->cones_tiles = a.tiles_w * geo.tiles_h;
                 c->defer->cones_cx = cones_cells ? c->cells_x : 0u; c->defer->cones_cy = cones_cells ? c->cells_y : 0u;
                 c->defer->cones_out = c->tile_cones.p;
-            } else {
-                launch_tile_cones(a, geo.tiles_h, cones_cells ? c->cells_x : 0u, cones_cells ? c->cells_y : 0u, c->tile_cones.p, st);
+                known = true;
             }
             c->cone_key = key;
         }
-        a.tile_cones = c->tile_cones.p; a.cones_cells = cones_cells;
+        a.tile_cones = c->tile_cones.p; a.cones_cells = cones_cells; a.cone_gen = c->cone_gen; a.cones_known = known ? 1 : 0;
     }
     const bool device_bin = c->tile_mode == TILES_DEVICE;
     // one fused kernel when a tile's cells fit one workgroup's waves; otherwise tile kernel + one-wave-per-cell kernel

@@ -200,7 +200,10 @@ struct BinArgs {
     // nullable: the tile cones and their cells' cones, two float4 per cone (axis, cos | sin, -, -, -), made by launch_tile_cones for these rays
     // and this tile geometry -- they depend on the camera only, so a frame with the camera of the last one reuses them
     // (otherwise every wave of the workgroup builds the tile's cone itself)
-    const float4 *tile_cones;
+    float4 *tile_cones;
+    uint32_t cone_gen;               // a row of tile_cones is valid if it carries this tag (second float4, .y): rows are filled by whoever needs them first --
+                                     // the list kernel's workgroups themselves (a camera that moves never pays a table launch) or tile_cones_kernel (batches)
+    int cones_known;                 // 0: the camera of this frame is new, no row can carry its tag: do not even read them
     uint32_t cones_cells;            // cells per tile the table holds cones for (row of tile t: t * (1 + cones_cells); 0: tile cones only)
     uint32_t *zero8;                 // nullable: 8 queue counters this launch clears for the kernels after it
     uint32_t *next_zero8;            // nullable: the OTHER counter set, cleared for the next list generation
@@ -216,7 +219,6 @@ struct FuseArgs {
 };
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st);
 void launch_build_chunks(uint32_t n, const float4 *mu_sig, const float4 *gB, float4 *chunks, hipStream_t st);
-void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uint32_t cells_y, float4 *cones_out, hipStream_t st);
 
 // Several frames per launch (vrt_hip_frame_batch_device): what one frame's three kernels take, as a row of a device array;
 // the batch variants of the kernels are the same code with blockIdx.y choosing the row.  A frame of a sparse scene is a

@@ -2116,20 +2116,22 @@ __device__ __forceinline__ Cone cell_cone(const BinArgs &P, uint32_t tx, uint32_
     };
     return rect_cone(at, x0, y0, x1, y1, lane);
 }
-// One wave per cone: per tile id its own cone (slot 0) and the cones of its cells (slots 1 .. cells per tile) -- what the
-// list kernel would build per workgroup and frame, once per camera.  Row = two float4: (axis, cos), (sin, -, -, -).
-__global__ __launch_bounds__(256) void tile_cones_kernel(BinArgs P, uint32_t n_tiles, uint32_t cells_x, uint32_t cells_y, float4 *out)
+// A row of the cone table: (axis, tag), (cos, sin, tag, -).  The tag (BinArgs::cone_gen) says which camera the row was made for; it sits in
+// BOTH halves, so a reader that catches a row between the writer's two stores sees two different tags and takes the row for missing.
+__device__ __forceinline__ void cone_row_write(float4 *table, size_t row, const Cone &k, uint32_t gen)
 {
-    const uint32_t per = 1 + cells_x * cells_y;
-    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k >= n_tiles * per) return;
-    const uint32_t t = k / per, c = k % per;
-    const Cone cn = c ? cell_cone(P, t % P.tiles_w, t / P.tiles_w, c - 1, cells_x, lane) : tile_cone(P, t % P.tiles_w, t / P.tiles_w, lane);
-    if (lane == 0) {
-        out[2 * k] = make_float4(cn.cx, cn.cy, cn.cz, cn.cos_t);
-        out[2 * k + 1] = make_float4(cn.sin_t, 0.f, 0.f, 0.f);
-    }
+    table[2 * row] = make_float4(k.cx, k.cy, k.cz, __uint_as_float(gen));
+    table[2 * row + 1] = make_float4(k.cos_t, k.sin_t, __uint_as_float(gen), 0.f);
 }
+__device__ __forceinline__ bool cone_row_read(const float4 *table, size_t row, uint32_t gen, Cone &k)
+{
+    const float4 c0 = table[2 * row], c1 = table[2 * row + 1];
+    if (__float_as_uint(c0.w) != gen || __float_as_uint(c1.z) != gen) return false;
+    k.cx = c0.x; k.cy = c0.y; k.cz = c0.z; k.cos_t = c1.x; k.sin_t = c1.y;
+    return true;
+}
+// One wave per cone: per tile id its own cone (slot 0) and the cones of its cells (slots 1 .. cells per tile) -- what the
+// list kernel's workgroups build (and file) themselves when they do not find them; frames of a batch get them from this one launch.
 __global__ __launch_bounds__(256) void tile_cones_batch_kernel(const FrameArgs *__restrict__ frames)
 {
     const FrameArgs &a = frames[blockIdx.y];
@@ -2140,10 +2142,7 @@ __global__ __launch_bounds__(256) void tile_cones_batch_kernel(const FrameArgs *
     if (k >= a.cones_tiles * per) return;
     const uint32_t t = k / per, c = k % per;
     const Cone cn = c ? cell_cone(P, t % P.tiles_w, t / P.tiles_w, c - 1, a.cones_cx, lane) : tile_cone(P, t % P.tiles_w, t / P.tiles_w, lane);
-    if (lane == 0) {
-        a.cones_out[2 * k] = make_float4(cn.cx, cn.cy, cn.cz, cn.cos_t);
-        a.cones_out[2 * k + 1] = make_float4(cn.sin_t, 0.f, 0.f, 0.f);
-    }
+    if (lane == 0) cone_row_write(a.cones_out, k, cn, P.cone_gen);
 }
 void launch_frame_setup_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st)
 {
@@ -2154,11 +2153,6 @@ void launch_frame_setup_batch(const FrameArgs *d_frames, const FrameArgs *h_fram
     }
     if (n_prep) hipLaunchKernelGGL(prep_frame_batch_kernel, dim3((n_prep + 255) / 256, nframes), dim3(256), 0, st, d_frames);
     if (n_cones) hipLaunchKernelGGL(tile_cones_batch_kernel, dim3((n_cones + 3) / 4, nframes), dim3(256), 0, st, d_frames);
-}
-void launch_tile_cones(const BinArgs &a, uint32_t tiles_h, uint32_t cells_x, uint32_t cells_y, float4 *cones_out, hipStream_t st)
-{
-    const uint32_t n = a.tiles_w * tiles_h * (1 + cells_x * cells_y);
-    if (n) hipLaunchKernelGGL(tile_cones_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a, a.tiles_w * tiles_h, cells_x, cells_y, cones_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2275,12 +2269,12 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     // farthest ray of a rectangle on the image plane from its centre ray is a corner ray)
     Cone cone = {};
     if (P.refine) {
-        if (P.tile_cones) { // made once for this camera (tile_cones_kernel)
-            const size_t row = (size_t)t * (1 + P.cones_cells);
-            const float4 c0 = P.tile_cones[2 * row], c1 = P.tile_cones[2 * row + 1];
-            cone.cx = c0.x; cone.cy = c0.y; cone.cz = c0.z; cone.cos_t = c0.w; cone.sin_t = c1.x;
-        } else {
+        bool have = false;
+        const size_t row = (size_t)t * (1 + P.cones_cells);
+        if (P.tile_cones && P.cones_known) have = cone_row_read(P.tile_cones, row, P.cone_gen, cone); // filed by an earlier frame with this camera (or by tile_cones_kernel)
+        if (!have) {
             cone = tile_cone(P, tx, ty, lane);
+            if (P.tile_cones && tid == 0) cone_row_write(P.tile_cones, row, cone, P.cone_gen);
         }
     }
 
@@ -2389,12 +2383,13 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         } else if (total) {
             Cone cc = {};
             if (P.refine) {
-                if (P.tile_cones && P.cones_cells == cpt) {
-                    const size_t row = (size_t)t * (1 + cpt) + 1 + ci;
-                    const float4 c0 = P.tile_cones[2 * row], c1 = P.tile_cones[2 * row + 1];
-                    cc.cx = c0.x; cc.cy = c0.y; cc.cz = c0.z; cc.cos_t = c0.w; cc.sin_t = c1.x;
-                } else {
+                bool have = false;
+                const size_t row = (size_t)t * (1 + cpt) + 1 + ci;
+                const bool tabled = P.tile_cones && P.cones_cells == cpt;
+                if (tabled && P.cones_known) have = cone_row_read(P.tile_cones, row, P.cone_gen, cc);
+                if (!have) {
                     cc = cell_cone(P, tx, ty, ci, C.cells_x, lane);
+                    if (tabled && lane == 0) cone_row_write(P.tile_cones, row, cc, P.cone_gen);
                 }
             }
             uint32_t *cout = C.indices + (size_t)cell * C.cstride;
