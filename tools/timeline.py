@@ -12,7 +12,9 @@ from sgrt_amd import scene
 cam, _ = scene.cli_camera(w, w)
 r = pkg.Renderer(0)
 r.set_gaussians(scene.grid_scene(grid)); r.set_camera_view(w, w, cam.view); r.tile_gaussians(2 / 16, 2 / 16, cam.view)
-for _ in range(3): r.render(cam.position, want_radiance=False)  # image only, like the frame path (16-byte clears)
+for _ in range(3):  # image only, like the frame path (16-byte clears); the lists are rebuilt per frame, as in a frame loop
+    r.tile_gaussians(2 / 16, 2 / 16, cam.view); r.render(cam.position, want_radiance=False)
 sys.stderr.write(f"# -g {grid} -w {w}: the frame below (third of three; pair lanes {os.environ.get('VRT_HIP_PAIR_LANES', '0')})\n"); sys.stderr.flush()
+r.tile_gaussians(2 / 16, 2 / 16, cam.view)   # (same camera: the cone table's rows are found)
 r.render(cam.position, want_radiance=False)
 r.close()
