@@ -19,7 +19,7 @@ constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate c
 #define VRT_PL 48
 #endif
 constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each; 96 since round 3 = the dense threshold: a block of
-                                  // this kernel never has more; the two kilobytes hold ln(sigma*mag*exp(-x)/eps) of the per-ray lists' entries for the budgeted prune)
+                                  // this kernel never has more; the two kilobytes went to the pair-lane path's rows of per-ray values)
 #ifndef VRT_DCAP
 #define VRT_DCAP 1024
 #endif
