@@ -52,7 +52,8 @@ def kernel_source_sha():
     """Identity of the kernel sources a profile was taken with (tools/pmc_traffic.py stores it in its summary)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("vrt_kernels.hip", "vrt_kernels.h", "vrt_device_math.h"):
+    for name in ("vrt_kernels_common.hpp", "vrt_block_kernel.hip", "vrt_table_kernel.hip", "vrt_kernels.hip", "vrt_kernels.h",
+                 "vrt_device_math.h"):
         with open(os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

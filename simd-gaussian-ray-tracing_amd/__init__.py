@@ -44,7 +44,7 @@ class Stats(C.Structure):
 def build(verbose=False):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-j4", "-C", os.path.join(_HERE, "csrc")], stdout=out)   # the two kernel translation units side by side
+    subprocess.check_call(["make", "-j4", "-C", os.path.join(_HERE, "csrc")], stdout=out)   # the three kernel translation units side by side
     return LIB_PATH
 
 

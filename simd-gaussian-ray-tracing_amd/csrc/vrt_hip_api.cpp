@@ -182,7 +182,15 @@ struct vrt_hip_ctx {
     // wrote the buffer (own_seq = 0: the next frame clears everything and starts a new history)
     DevBuf<uint32_t> own_stamp;
     uint32_t own_seq = 0;
-    uint64_t own_sig = 0;
+    struct OwnGeometry { // what a retained history is valid for: compared field by field (a hash of overlapping fields let two tile grids collide)
+        uint32_t w = 0, h = 0, tiles_w = 0, tiles_h = 0, tile_w = 0, tile_h = 0, background = 0;
+        const uint32_t *image = nullptr;
+        bool operator==(const OwnGeometry &o) const
+        {
+            return w == o.w && h == o.h && tiles_w == o.tiles_w && tiles_h == o.tiles_h && tile_w == o.tile_w && tile_h == o.tile_h &&
+                   background == o.background && image == o.image;
+        }
+    } own_sig;
     bool retain_next = false; // set by vrt_hip_frame around its render_common call
     DevBuf<uint32_t> d_image;
     DevBuf<float4> d_rad;
@@ -835,16 +843,23 @@ int retained_begin(vrt_hip_ctx *c, uint32_t *image, float tw, float th, int pack
     const uint32_t tile_w = (uint32_t)(uint64_t)(c->w * tw / 2.f), tile_h = (uint32_t)(uint64_t)(c->h * th / 2.f);
     const uint32_t cx = (tile_w + CELL - 1) / CELL, cy = (tile_h + CELL - 1) / CELL;
     const size_t cells = (size_t)tiles_w * tiles_h * cx * cy;
-    const uint64_t sig = ((uint64_t)c->w << 40) ^ ((uint64_t)c->h << 20) ^ ((uint64_t)tiles_w << 52) ^ ((uint64_t)tiles_h << 8) ^ ((uint64_t)tile_w << 30) ^
-                         tile_h ^ ((pack_flags & VRT_ALPHA_COMPUTED) ? 1ull << 63 : 0ull) ^ (uint64_t)(uintptr_t)image * 0x9E3779B97F4A7C15ull;
+    vrt_hip_ctx::OwnGeometry sig;
+    sig.w = c->w; sig.h = c->h; sig.tiles_w = tiles_w; sig.tiles_h = tiles_h; sig.tile_w = tile_w; sig.tile_h = tile_h;
+    sig.background = (pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u; sig.image = image;
     static const bool retain_on = [] { const char *e = getenv("VRT_HIP_RETAIN_FRAME"); return !e || atoi(e) != 0; }();
     c->retain_next = retain_on && cells > 0 && cells < (1u << 28) && tiles_w <= 4096 && tiles_h <= 4096 && c->world == 1;
     if (!c->retain_next) { c->own_seq = 0; return VRT_HIP_OK; }
-    if (sig != c->own_sig || c->own_seq == 0 || c->own_seq >= 0xFFFFFFF0u || c->own_stamp.cap < cells) {
+    if (c->last_stream && c->last_stream != st) {
+        // the previous frame ran on another stream: its list and block kernels may still be writing the stamps and the image that the
+        // memsets below reset on THIS stream (render_common's own hand-over comes after this function)
+        if (hipStreamSynchronize(c->last_stream) != hipSuccess) (void)hipGetLastError();
+        c->last_stream = st;
+    }
+    if (!(sig == c->own_sig) || c->own_seq == 0 || c->own_seq >= 0xFFFFFFF0u || c->own_stamp.cap < cells) {
         if (c->own_stamp.cap < cells) { int rc = quiesce(c); if (rc) return rc; } // frames in flight write the old stamp buffer
         HIPCHK(c, c->own_stamp.reserve(cells));
         HIPCHK(c, hipMemsetAsync(c->own_stamp.p, 0, cells * sizeof(uint32_t), st));
-        if (sig != c->own_sig) HIPCHK(c, hipMemsetAsync(image, 0, npix * 4, st)); // pixels no tile of the NEW grid covers read 0
+        if (!(sig == c->own_sig)) HIPCHK(c, hipMemsetAsync(image, 0, npix * 4, st)); // pixels no tile of the NEW grid covers read 0
         c->own_sig = sig;
         c->own_seq = 1; // stamps of 0 = "never lit": with seq 1 every empty cell compares against 0 = seq - 1 and is cleared
     } else {
@@ -1463,6 +1478,7 @@ int vrt_hip_set_shard(vrt_hip_ctx *c, int rank, int world)
 {
     if (!c) return VRT_HIP_ERR_INVALID;
     if (world < 1 || rank < 0 || rank >= world) return fail(c, VRT_HIP_ERR_INVALID, "set_shard: bad rank/world");
+    if (rank != c->rank || world != c->world) ++c->state_gen; // vrt_hip_copy_state copies rank / world: holders of mirrors must see the change
     c->rank = rank; c->world = world; c->shard_dirty = true; c->lists_dirty = true; c->reset_seq = c->frame_seq;
     return VRT_HIP_OK;
 }

@@ -1,0 +1,577 @@
+// vrt_table_kernel.hip -- the table kernel: dense blocks through a per-ray table of the transmittance exponent.  A translation unit
+// of its own (the three kernel units compile side by side); the default scheduler (csrc/Makefile has the measurement).
+// gfx950 only: TableLds takes ~152 KB of the CU's 160 KB of LDS (static_assert below).
+#include "vrt_kernels_common.hpp"
+
+namespace vrtk {
+
+// ---------------------------------------------------------------------------------------------
+// Table mode (default; vrt_hip_set_table_step(0) = the exact kernels only): dense blocks through a per-ray TABLE of the
+// transmittance exponent.  Along one ray  X(s) = sum_j A_j (E_j - Erf(s r_j - m_j))  is ONE function of s, and the radiance
+// needs it at 5 n points (five samples per emitter).  The exact kernel evaluates every one of them term by term: 5 n^2 erf
+// terms per ray.  Here X is evaluated at G equidistant nodes of the ray's sample range (n G terms) and the 5 n samples are
+// read off by 4-point Lagrange interpolation.
+//
+// Error control.  The Abramowitz-Stegun erf has a jump of 0.586 in its second derivative at 0 (it is an odd extension of a
+// rational function), so X has a kink at every mubar_j.  For a unit erf tabulated with node spacing u (in units of 1/r_j) the
+// 4-point interpolant is off by at most 0.0212 u^2 where the stencil contains the kink -- less, by a known factor w <= 1, depending
+// on where in the stencil it lies (TB_W0 below) -- and by at most 0.36 u^4 where it does not (tools/table_error_study.py, all phases,
+// u <= 0.3).  So for a sample s in node interval g
+//     |dX(s)| <= 0.0212 u^2 * K(g) + 0.36 u^4 * S_all,   K(g) = sum of w_j |A_j| over the kinks in intervals g-1 .. g+1,  S_all = sum_j |A_j|,
+// and a ray's radiance moves by at most  sum_ik |albedo_i|max * |term_ik| * |dX(s_ik)|  (term_ik = the emission sample).
+// The kernel accumulates exactly this sum per ray (K from a per-ray pass over the A_j, kept as one byte per node) and
+// keeps a block only if every ray stays below the budget (CellGrid::table_budget, default 2.5e-5: with the cull thresholds'
+// 2.5e-5 the frame's worst case is 5e-5, half the 1e-4 tolerance).  A block that fails is tried once more at 0.6 of the
+// spacing and then handed to the exact kernel (second queue), as are blocks with more than 2048 survivors or a sample range
+// of more than 8 x 376 nodes.  The bound is a worst case (every kink at its worst phase,
+// all errors aligned): measured deviations are 20-30 x smaller.
+//
+// Work split: 16 waves hold the same 64 rays (lane = ray).  Wave w owns the contiguous nodes [w NT, (w+1) NT): an absorber
+// whose erf is saturated (exactly -1 or +1, erf_saturation<>) over that whole range on all 64 rays costs one add.  The
+// per-(ray, absorber) set-up (A_j, m_j: a dot product, an Exp) is made ONCE per block, 16 absorbers at a time into LDS
+// (wave w stages absorber w of the chunk), instead of by every wave for its own nodes.
+// ---------------------------------------------------------------------------------------------
+constexpr int TB_TC = 2048, TB_GMAX = 384, TB_CH = 16, TB_DW = 16;
+static_assert(TB_CH == TB_DW, "one staged absorber per wave and chunk");
+// Per-kink error bound of the 4-point interpolant, in units of u^2 |A_j| (tools/table_error_study.py verifies the constants
+// for u <= 0.3, all phases): a kink at offset theta in [0, 1) of its node interval moves the interpolant by at most
+//   TB_W0 min(1, 0.28 + 2.58 |theta - 1/2|) u^2 in that interval, TB_W0 theta^2 u^2 in the interval to its right,
+//   TB_W0 (1 - theta)^2 u^2 in the one to its left, and by at most TB_COUT u^4 anywhere else.
+constexpr float TB_W0 = 0.0212f, TB_COUT = 0.36f;
+struct TableLds {
+    uint32_t idx[TB_TC];                       //  8 KB: the block's survivors, in list order (their rows come from the tables by
+                                               //        wave-uniform loads: every pass below needs a row once per wave)
+    union {                                    // 96 KB: X at node g of lane l; before that the kink weights per interval (fixed point);
+        float tab[TB_GMAX][64];                //        after the emission pass the partial error sums
+        uint32_t hist[TB_GMAX][64];
+    };
+    uint8_t s3[TB_GMAX][64];                   // 24 KB: kink weight of interval g / S_all in 1/255, rounded up
+    union {                                    // 24 KB
+        struct { float A[2][TB_CH][64], M[2][TB_CH][64], E[2][TB_CH][64]; } st;   // staged set-up, double-buffered
+        float4 L[TB_DW][64];                                     // partial radiances
+        float red[4][TB_DW][64];                                 // partial sums of the range and histogram passes
+    };
+    float st_r[2][TB_CH];                      // r_j of the staged absorbers
+};
+
+// one pass over the survivors for the NT nodes [g0, g0 + NT) of this wave; tab[g] = sum_j A_j (E_j - Erf(x_gj)), summed per term
+// like the exact kernels (C - sum A_j Erf would round at the magnitude of sum |A_j|: 5e-5 of radiance for 1500 wide Gaussians,
+// tests/fuzz_parity.py seed 3 case 6)
+template <int EXP, int ERF, int NT>
+__device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds, uint32_t cnt, const LaneRay &ray,
+                                            float s_first /* node g0 of this lane */, float h, uint32_t g0, uint32_t wave,
+                                            uint32_t lane, uint32_t &n_skip)
+{
+    constexpr float SAT_M = erf_saturation<ERF>() + 1e-3f;
+    const ErfEval<ERF> erf;
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    float common = 0.f;
+    // Staging: wave w computes (A, m, E) of absorber w of a chunk for its 64 rays.  The absorber's two parameter rows come by
+    // wave-uniform loads issued one chunk AHEAD of their use (fetch(c + 2) before the node loop of chunk c): their latency --
+    // the longest single wait of a small block -- hides behind the erf terms.
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+    bool pv = false;
+    auto fetch = [&](uint32_t chunk) {
+        const uint32_t j = chunk * TB_CH + wave;
+        pv = j < cnt; // wave-uniform
+        if (pv) {
+            const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
+            pa = uload(S.gA, idx); pb = uload(S.gB, idx);
+        }
+    };
+    auto stage = [&](uint32_t chunk) { // from the rows fetched last
+        const uint32_t b = chunk & 1u;
+        float A = 0.f, m = 0.f, r = 0.f, E = 0.f;
+        if (pv) {
+            const float mubar = dot3_ref(pa.x, pa.y, pa.z, ray.nx, ray.ny, ray.nz);
+            const float d2 = sub_ref(pa.w, mul_ref(mubar, mubar));
+            A = pb.z * vexp<EXP>(-(d2 * pb.y));
+            m = mubar * pb.x;
+            E = erf(-m);
+            r = pb.x;
+        }
+        lds.st.A[b][wave][lane] = A; lds.st.M[b][wave][lane] = m; lds.st.E[b][wave][lane] = E;
+        if (lane == 0) lds.st_r[b][wave] = r;
+    };
+    const uint32_t chunks = (cnt + TB_CH - 1) / TB_CH;
+    fetch(0);
+    stage(0);
+    if (chunks > 1) fetch(1);
+    __syncthreads();
+    for (uint32_t c = 0; c < chunks; ++c) {
+        if (c + 1 < chunks) {
+            stage(c + 1);
+            if (c + 2 < chunks) fetch(c + 2);
+        }
+        const uint32_t b = c & 1u, nj = min((uint32_t)TB_CH, cnt - c * TB_CH);
+        // the next absorber's staged values are requested one iteration ahead (LDS latency behind the erf terms)
+        float nA = lds.st.A[b][0][lane], nM = lds.st.M[b][0][lane], nE = lds.st.E[b][0][lane], nR = lds.st_r[b][0];
+        for (uint32_t jj = 0; jj < nj; ++jj) {
+            const float A = nA, m = nM, E = nE, r = nR;
+            if (jj + 1 < nj) { nA = lds.st.A[b][jj + 1][lane]; nM = lds.st.M[b][jj + 1][lane]; nE = lds.st.E[b][jj + 1][lane]; nR = lds.st_r[b][jj + 1]; }
+            const float hr = h * r;
+            const float x0 = __builtin_fmaf(s_first, r, -m), x1 = __builtin_fmaf((float)(NT - 1), hr, x0);
+            // Four wave-uniform questions about the argument range [x0, x1] of this wave's nodes on all rays, asked together (one
+            // after the other each would wait for its own vector compare to reach the scalar unit: a quarter of a small block's
+            // node loop): saturated -- Erf = -1 (the absorber lies behind the nodes) or +1 (in front): one fma; or of ONE sign (all
+            // but the absorbers whose kink lies inside the range): Erf = +-(1 - R), so E - Erf = (E - 1) + R or (E + 1) - R -- ten
+            // instructions per term instead of twelve, no sign transfer (v_bfi_b32: 4.3 issue cycles)
+            const bool sat_lo = __all(x1 <= -SAT_M), sat_hi = __all(x0 >= SAT_M);
+            const bool all_pos = ERF == VRT_ERF_AS && __all(x0 >= 0.f), all_neg = ERF == VRT_ERF_AS && __all(x1 <= 0.f);
+            if (sat_lo | sat_hi) {
+                common = __builtin_fmaf(A, sat_lo ? E + 1.f : E - 1.f, common);
+                ++n_skip;
+            } else if (all_pos) {
+                if constexpr (ERF == VRT_ERF_AS) {
+                    const float Em1 = E - 1.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Em1 + erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+                }
+            } else if (all_neg) {
+                if constexpr (ERF == VRT_ERF_AS) {
+                    const float Ep1 = E + 1.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Ep1 - erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+            }
+        }
+        __syncthreads(); // chunk c+1 is staged, and everyone is done with buffer b (chunk c+2 goes there)
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (g0 + t < (uint32_t)TB_GMAX) lds.tab[g0 + t][lane] = acc[t] + common;
+}
+
+template <int EXP, int ERF>
+__device__ __forceinline__ void render_table_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R,
+                                                  const RenderTarget &O)
+{
+    constexpr int DW = TB_DW, TC = TB_TC;
+    __shared__ TableLds lds;
+    __shared__ uint32_t s_wave_cnt[DW];
+    __shared__ float s_rmax[DW];
+    __shared__ uint32_t s_item, s_flag;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t npix = (uint64_t)R.width * R.height;
+    const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
+    if (C.feedback && blockIdx.x == 0 && tid == 0) {
+        __hip_atomic_store(&C.feedback[2], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&C.feedback[3], C.frame_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const uint32_t *dense_queue = C.dense_is_sorted ? C.dense_sorted : C.dense;
+    uint32_t n_skip = 0; // (absorber, wave) visits the saturation test settled with one add (statistics)
+
+    for (;;) {
+        __syncthreads(); // everyone is done with the previous item's LDS
+        if (tid == 0) s_item = atomicAdd(C.dense_next, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= n_items) break;
+        // phase clock (statistics runs only): thread 0 adds the time since the last stamp to stats[24 + phase]
+        unsigned long long t_last = (O.stats && tid == 0) ? wall_clock64() : 0ull;
+        auto stamp = [&](int phase) {
+            if (O.stats && tid == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&O.stats[24 + phase], t - t_last); t_last = t; }
+        };
+        uint32_t cell, bi;
+        if (item < n_dense16) { cell = dense_queue[item >> 4]; bi = item & 15u; }
+        else { const uint32_t packed = C.overflow[item - n_dense16]; cell = packed >> 4; bi = packed & 15u; }
+        const BlockPos p = block_of(T, C, O, cell, bi, lane);
+        if (!p.inside) continue;
+        const uint32_t tx = p.t % T.tiles_w, ty = p.t / T.tiles_w;
+        bool valid = p.pxt < T.tile_w && p.pyt < T.tile_h;
+        const uint32_t pxc = min(p.pxt, T.tile_w - 1), pyc = min(p.pyt, T.tile_h - 1);
+        uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
+        if (pix >= npix) { valid = false; pix = npix - 1; }
+        const uint32_t n_active_cells = *C.n_active;
+        const uint64_t out = out_index(T, C, O, cell, bi, lane, p, pix, n_active_cells);
+        if (O.sparse && item < n_dense16 && bi == 0 && tid == 0) // a dense cell's key (the active cells' are filed by the list kernel)
+            O.keys[n_active_cells + (C.slot[cell] & 0x7FFFFFFFu)] = p.t * (C.cells_x * C.cells_y) + cell % (C.cells_x * C.cells_y);
+
+        uint32_t n_list = C.count[cell];
+        const uint32_t *list = C.indices + (size_t)cell * C.cstride;
+        if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
+
+        const LaneRay ray = pixel_ray(R, pix); // every wave holds the same 64 rays
+        float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
+        float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
+        float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
+        {
+            const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy + cz * cz);
+            cx *= inv; cy *= inv; cz *= inv;
+        }
+        float co, si;
+        cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
+        const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
+        stamp(0);
+
+        // ---- cooperative block cull, order preserving across the 16 waves (as in the exact kernel) ----
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < n_list; base += DW * 64) {
+            const uint32_t k = base + tid;
+            bool keep = false;
+            uint32_t idx = 0;
+            if (k < n_list) {
+                idx = list[k];
+                float4 bq = S.gB[idx];
+                bq.w = slack_cull_x(bq.w, level_slack(T.cull_ref_n, n_list), T.floor_x);
+                keep = cone_keeps(cone, S.gA[idx], bq);
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+            __syncthreads();
+            uint32_t before = 0, chunk = 0;
+#pragma unroll
+            for (uint32_t wv = 0; wv < DW; ++wv) {
+                const uint32_t c = s_wave_cnt[wv];
+                before += (wv < wave) ? c : 0;
+                chunk += c;
+            }
+            const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            if (keep && pos < TC) lds.idx[pos] = idx;
+            cnt += chunk;
+            __syncthreads();
+        }
+
+        stamp(1);
+        if (cnt == 0) { // nothing reaches this block (the rim of a dense cell): background
+            if (wave == 0 && valid) {
+                if (O.image) O.image[out] = pack_pixel(0.f, 0.f, 0.f, 0.f, O.pack_flags);
+                if (O.radiance) O.radiance[out] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (O.stats && tid == 0) { atomicAdd(&O.stats[1], (unsigned long long)n_list); atomicAdd(&O.stats[6], 1ull); atomicAdd(&O.stats[7], 1ull); atomicAdd(&O.stats[21], 1ull); }
+            continue;
+        }
+        // ---- every ray's sample range (wave w looks at survivors w, w + 16, ...), the block's node spacing ----
+        bool ok = cnt <= (uint32_t)TC;
+        float s_lo = INFINITY, s_hi = -INFINITY, r_max = 0.f;
+        if (ok) {
+            // (rows by wave-uniform loads, the next iteration's requested before this one's arithmetic: here and in the passes below)
+            float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+            if (wave < cnt) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[wave]); na = uload(S.gA, i0_); nb = uload(S.gB, i0_); }
+            for (uint32_t j = wave; j < cnt; j += DW) {
+                const float4 a = na;
+                const float r = nb.x;
+                if (j + DW < cnt) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[j + DW]); na = uload(S.gA, in_); nb = uload(S.gB, in_); }
+                const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+                s_hi = fmaxf(s_hi, mubar);
+                s_lo = fminf(s_lo, mubar - 2.8285f / r); // mubar - 4 sigma, sigma = 1/(sqrt2 r), rounded outwards
+                r_max = fmaxf(r_max, r);
+            }
+            lds.red[0][wave][lane] = s_hi; lds.red[1][wave][lane] = s_lo;
+            if (lane == 0) s_rmax[wave] = r_max;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < DW; ++w) {
+                s_hi = fmaxf(s_hi, lds.red[0][w][lane]); s_lo = fminf(s_lo, lds.red[1][w][lane]);
+                r_max = fmaxf(r_max, s_rmax[w]);
+            }
+            __syncthreads();
+        }
+        stamp(2);
+        const float range = wave_max(s_hi - s_lo); // the block's longest sample range
+        const float h_req = C.table_hx / r_max;    // requested spacing: table_hx in units of 1/r of the narrowest Gaussian
+        ok = ok && range >= 0.f && h_req > 0.f && range < INFINITY; // (false for NaN)
+        bool done = false;
+        float h_target = h_req;
+        for (int attempt = 0; ok && !done; ++attempt) {
+            // Every ray has its own grid of Gtot nodes from its first sample on (two nodes of margin at either end, so that
+            // every sample has its four neighbours), all with the block's spacing.  The table holds TB_GMAX nodes: a deeper
+            // range is worked off in segments of SL intervals (+ the margins); a sample belongs to the segment its interval
+            // lies in.  Segments in empty space cost next to nothing: every absorber is saturated there.  The waves evaluate
+            // NT nodes each, NT from a short menu: the spacing is then REDUCED until the segments fill 16 NT nodes exactly.
+            float h = 0.f, u = 0.f, lo = 0.f, inv_h = 0.f;
+            uint32_t nseg = 0, SL = 0, G = 0, NTsel = 0, Gtot = 0;
+            auto plan = [&](float ht) -> bool {
+                const float need = ceilf(range / ht); // intervals the samples span
+                if (!(need < 8.f * (float)(TB_GMAX - 8))) return false;
+                nseg = max(1u, ((uint32_t)need + (uint32_t)(TB_GMAX - 8) - 1u) / (uint32_t)(TB_GMAX - 8));
+                const uint32_t sl_need = max(1u, ((uint32_t)need + nseg - 1u) / nseg);
+                const uint32_t nt = (sl_need + 8u + DW - 1) / DW;
+                NTsel = nt <= 4 ? 4 : nt <= 6 ? 6 : nt <= 8 ? 8 : nt <= 12 ? 12 : nt <= 16 ? 16 : nt <= 20 ? 20 : 24;
+                // intervals per segment; nodes in the table: the segment's intervals, two nodes before them, and up to six behind
+                // the last one (the samples' intervals start at 2 and end at Gtot - 4 <= nseg SL + 2, whose stencil ends at nseg SL + 4)
+                G = NTsel * DW; SL = G - 8u;
+                h = fminf(ht, range / (float)(nseg * SL) * 1.00001f);
+                if (!(h > 0.f)) h = ht; // range == 0: one sample point per ray
+                u = h * r_max;
+                Gtot = nseg * SL + 6u;
+                lo = s_lo - 2.f * h; inv_h = 1.f / h;
+                return u <= 0.3f;
+            };
+            if (!plan(h_target)) { ok = false; break; }
+
+            float S_all = 0.f;
+            // ---- kink pass for one segment: wave w takes absorbers w, w + 16, ...: the weight of the kink of j (TB_W0 units,
+            //      fixed point, rounded up; integer adds: the order of the atomics does not matter) into the interval of mubar_j
+            //      and its two neighbours; with `sums` also S_all = sum |A_j| ----
+            auto kink_pass = [&](uint32_t seg, bool sums) {
+                const float node0 = (float)(seg * SL) - 2.f; // the segment's first node on the ray's grid
+                for (uint32_t g = wave; g < G; g += DW) lds.hist[g][lane] = 0u;
+                __syncthreads();
+                float s_part = 0.f;
+                float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+                if (wave < cnt) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[wave]); na = uload(S.gA, i0_); nb = uload(S.gB, i0_); }
+                for (uint32_t j = wave; j < cnt; j += DW) {
+                    const float4 ca = na, cb = nb;
+                    if (j + DW < cnt) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[j + DW]); na = uload(S.gA, in_); nb = uload(S.gB, in_); }
+                    const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+                    const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+                    const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
+                    if (sums) s_part += fabsf(A);
+                    const float pos = (mubar - lo) * inv_h;
+                    const float gb = floorf(pos);
+                    const float th = fminf(fmaxf(pos - gb, 0.f), 1.f);
+                    const float a16 = fminf(fabsf(A), 60.f) * 65536.f;
+                    const float gl = gb - node0; // interval of the kink in this segment's table
+                    if (gl >= 0.f && gl < (float)G) atomicAdd(&lds.hist[(uint32_t)gl][lane], (uint32_t)ceilf(a16 * fminf(1.f, 0.28f + 2.58f * fabsf(th - 0.5f))));
+                    if (gl + 1.f >= 0.f && gl + 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl + 1.f)][lane], (uint32_t)ceilf(a16 * th * th));
+                    if (gl - 1.f >= 0.f && gl - 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl - 1.f)][lane], (uint32_t)ceilf(a16 * (1.f - th) * (1.f - th)));
+                }
+                if (sums) lds.red[3][wave][lane] = s_part;
+                __syncthreads();
+                if (sums) {
+                    S_all = 0.f;
+#pragma unroll
+                    for (int w = 0; w < DW; ++w) S_all += lds.red[3][w][lane];
+                }
+            };
+
+            // ---- first attempt: how much coarser than requested may the nodes be?  An ESTIMATE of the bound the emission pass
+            //      will find, from the kink weights at the requested spacing: emission of interval g ~ 1.4 D_g T_g with
+            //      D_g = K_g / 1.35 the absorber mass of the interval and T_g = exp(-2 sum of the mass before it); the estimate
+            //      scales with the spacing like kappa^3 (kink part) and kappa^4 (smooth part).  It only picks the spacing: the
+            //      bound itself is checked below, and a block that fails it is redone at 0.6 of the spacing. ----
+            bool have_kinks = false; // the kink weights of segment 0 at the final spacing are in LDS
+            bool have_sums = false;  // S_all is known (it does not depend on the spacing)
+            if (attempt == 0 && C.table_adapt > 1.f) {
+                float P = 0.f, pin = 0.f, pout = 0.f;
+                for (uint32_t seg = 0; seg < nseg; ++seg) {
+                    kink_pass(seg, seg == 0);
+                    const uint32_t ga = seg ? 2u : 0u, gz = min(G, SL + 2u); // the segment's own intervals
+                    const uint32_t wa = min(gz, ga + wave * NTsel), wz = min(gz, wa + NTsel);
+                    float mass = 0.f;
+                    for (uint32_t g = wa; g < wz; ++g) mass += (float)lds.hist[g][lane];
+                    lds.red[0][wave][lane] = mass * (1.f / (1.35f * 65536.f));
+                    __syncthreads();
+                    float before = P, total = 0.f;
+#pragma unroll
+                    for (int w = 0; w < DW; ++w) {
+                        const float mw = lds.red[0][w][lane];
+                        before += (uint32_t)w < wave ? mw : 0.f;
+                        total += mw;
+                    }
+                    for (uint32_t g = wa; g < wz; ++g) {
+                        const float Kg = (float)lds.hist[g][lane] * (1.f / 65536.f), D = Kg * (1.f / 1.35f);
+                        const float e = 1.4f * D * __expf(-2.f * before);
+                        pin = __builtin_fmaf(e, Kg, pin); pout += e;
+                        before += D;
+                    }
+                    P += total;
+                    __syncthreads(); // red[0] is rewritten by the next segment
+                }
+                have_sums = true;
+                lds.red[0][wave][lane] = pin; lds.red[1][wave][lane] = pout;
+                __syncthreads();
+                float pin_t = 0.f, pout_t = 0.f;
+#pragma unroll
+                for (int w = 0; w < DW; ++w) { pin_t += lds.red[0][w][lane]; pout_t += lds.red[1][w][lane]; }
+                const float est_in = 1.01f * TB_W0 * u * u * pin_t, est_out = 1.01f * TB_COUT * (u * u) * (u * u) * S_all * pout_t;
+                float kappa = 1.f;
+                const float room = C.table_room * C.table_budget;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const float k = c == 0 ? 3.f : c == 1 ? 2.5f : c == 2 ? 2.f : c == 3 ? 1.6f : 1.3f;
+                    if (kappa == 1.f && k <= C.table_adapt && k * u <= 0.3f && k * k * k * (est_in + k * est_out) <= room) kappa = k;
+                }
+                kappa = wave_min(valid ? kappa : 3.f); // the same in every wave: they hold the same rays
+                __syncthreads();
+                const float h_before = h;
+                const uint32_t nodes_before = nseg * NTsel, nseg_before = nseg;
+                if (kappa > 1.f && (!plan(h * kappa) || nseg * NTsel >= nodes_before)) { // the menu has no smaller table: as requested
+                    if (!plan(h_target)) { ok = false; break; }
+                }
+                have_kinks = h == h_before && nseg_before == 1u; // segment 0's weights at this spacing are still in LDS
+                if (O.stats && tid == 0 && h != h_before) atomicAdd(&O.stats[20], 1ull);
+            }
+            stamp(3);
+            const uint32_t g0 = wave * NTsel;
+            float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f, b_in = 0.f, b_out = 0.f;
+
+            for (uint32_t seg = 0; seg < nseg; ++seg) {
+                const float node0 = (float)(seg * SL) - 2.f; // the segment's first node on the ray's grid
+                if (!(seg == 0 && have_kinks)) kink_pass(seg, seg == 0 && !have_sums);
+                const float s3_scale = 255.f / (fmaxf(S_all, 1e-30f) * 65536.f);
+                for (uint32_t g = wave; g < G; g += DW)
+                    lds.s3[g][lane] = (uint8_t)fminf(floorf((float)lds.hist[g][lane] * s3_scale) + 1.f, 255.f);
+                __syncthreads(); // the weights are read: their memory becomes the table; the partial sums' memory the staging buffers
+                stamp(4);
+
+                // ---- table: wave w evaluates the nodes [w NT, (w+1) NT) of the segment against all survivors ----
+                const float s_first = __builtin_fmaf(node0 + (float)g0, h, lo);
+                switch (NTsel) {
+                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                }
+                __syncthreads();
+                stamp(5);
+
+                // ---- emission: the emitters are dealt to the waves; X(s_ik) by 4-point Lagrange interpolation for the samples
+                //      of this segment; the error bound is accumulated beside the radiance ----
+                const float seg_lo = (float)(seg * SL), seg_hi = seg + 1 == nseg ? INFINITY : (float)((seg + 1) * SL);
+                // (emitter i of wave w: w, w + 16, ...; the five rows of the NEXT emitter are requested before this one's samples)
+                struct Rows { float4 a, ms, alb; float inv2s2, q; } nx = {};
+                auto fetch_rows = [&](uint32_t i) {
+                    const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[i]);
+                    nx.a = uload(S.gA, idx); nx.ms = uload(S.mu_sig, idx); nx.alb = uload(S.gC, idx);
+                    nx.inv2s2 = uload(S.gB, idx).y; nx.q = uload(S.gD, idx).y;
+                };
+                if (wave < cnt) fetch_rows(wave);
+                for (uint32_t i = wave; i < cnt; i += DW) {
+                    {
+                        const Rows cur = nx;
+                        if (i + DW < cnt) fetch_rows(i + DW);
+                        const float4 a = cur.a, ms = cur.ms, alb = cur.alb;
+                        const float inv2s2 = cur.inv2s2, q = cur.q;
+                        const float e_mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+                        float inner = 0.f, inner_abs = 0.f, inner_s3 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const float sk = madd_ref((float)(k - 4), ms.w, e_mubar);
+                            const float uu = (sk - lo) * inv_h;
+                            const float gi = fminf(fmaxf(floorf(uu), 2.f), (float)(Gtot - 4)); // interval on the ray's grid
+                            const bool mine = nseg == 1 || (gi >= seg_lo && gi < seg_hi);
+                            const float gfl = mine ? gi - node0 : 2.f; // ... and in the table
+                            const float t = uu - (gfl + node0);
+                            const uint32_t g = (uint32_t)gfl;
+                            const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
+                            const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
+                            const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
+                            const float dd = dot3_ref(px, py, pz, px, py, pz);
+                            const float tm1 = t - 1.f, tm2 = t - 2.f, tp1 = t + 1.f;
+                            const float w0 = t * tm1 * tm2 * (-1.f / 6.f), w1 = tp1 * tm1 * tm2 * 0.5f;
+                            const float w2 = tp1 * t * tm2 * -0.5f, w3 = tp1 * t * tm1 * (1.f / 6.f);
+                            const float X = w0 * lds.tab[g - 1][lane] + w1 * lds.tab[g][lane] + w2 * lds.tab[g + 1][lane] + w3 * lds.tab[g + 2][lane];
+                            const float term = mine ? emission_term<EXP>(q, dd * inv2s2, X) : 0.f;
+                            inner += term;
+                            inner_abs += fabsf(term);
+                            inner_s3 = __builtin_fmaf(fabsf(term), (float)lds.s3[g][lane], inner_s3);
+                        }
+                        Lr = __builtin_fmaf(alb.x, inner, Lr);
+                        Lg = __builtin_fmaf(alb.y, inner, Lg);
+                        Lb = __builtin_fmaf(alb.z, inner, Lb);
+                        La = __builtin_fmaf(alb.w, inner, La);
+                        const float amax = fmaxf(fmaxf(fabsf(alb.x), fabsf(alb.y)), fmaxf(fabsf(alb.z), fabsf(alb.w)));
+                        b_in = __builtin_fmaf(amax, inner_s3, b_in);
+                        b_out = __builtin_fmaf(amax, inner_abs, b_out);
+                    }
+                }
+                __syncthreads(); // nobody reads the staging buffers or the table any more
+                stamp(6);
+            }
+            lds.L[wave][lane] = make_float4(Lr, Lg, Lb, La);
+            float2 *bparts = reinterpret_cast<float2 *>(&lds.tab[0][0]); // [DW][64]
+            bparts[wave * 64 + lane] = make_float2(b_in, b_out);
+            __syncthreads();
+            if (wave == 0) {
+                float4 sum = lds.L[0][lane];
+                float2 bs = bparts[lane];
+#pragma unroll
+                for (int w = 1; w < DW; ++w) {
+                    const float4 v = lds.L[w][lane];
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    const float2 bv = bparts[w * 64 + lane];
+                    bs.x += bv.x; bs.y += bv.y;
+                }
+                // worst-case change of this ray's radiance (header comment); e^dX - 1 <= 1.01 dX for the dX in question
+                const float e_in = TB_W0 * u * u, e_out = TB_COUT * (u * u) * (u * u);
+                const float bound = 1.01f * S_all * (e_in * (1.f / 255.f) * bs.x + e_out * bs.y);
+                // (false for NaN; S_all beyond the fixed-point range of the weights: no bound)
+                const bool good = !valid || (bound <= C.table_budget && S_all < 60.f);
+                const bool all_good = __all(good);
+                if (all_good && valid) {
+                    if (O.image) O.image[out] = pack_pixel(sum.x, sum.y, sum.z, sum.w, O.pack_flags);
+                    if (O.radiance) O.radiance[out] = sum;
+                }
+                if (lane == 0) s_flag = all_good ? 1u : 0u;
+            }
+            __syncthreads();
+            stamp(7);
+            done = s_flag != 0u;
+            if (!done) {
+                if (attempt >= 1) { ok = false; break; }
+                h_target = 0.6f * h;
+            } else if (O.stats && tid == 0) {
+                atomicAdd(&O.stats[0], (unsigned long long)cnt);
+                atomicAdd(&O.stats[1], (unsigned long long)n_list);
+                atomicAdd(&O.stats[6], 1ull);
+                atomicAdd(&O.stats[7], 1ull);
+                atomicAdd(&O.stats[16], (unsigned long long)Gtot);
+                if (attempt) atomicAdd(&O.stats[17], 1ull);
+            }
+        }
+        if (!ok) { // wave-uniform and the same in every wave
+            if (tid == 0) {
+                C.overflow2[atomicAdd(C.n_overflow2, 1u)] = (cell << 4) | bi;
+                if (O.stats) atomicAdd(&O.stats[19], 1ull);
+            }
+            continue;
+        }
+    }
+    if (O.stats && lane == 0) atomicAdd(&O.stats[18], (unsigned long long)n_skip);
+}
+
+template <int EXP, int ERF>
+__global__ __launch_bounds__(1024) void render_table_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+{
+    render_table_body<EXP, ERF>(S, T, C, R, O);
+}
+// several frames per launch: blockIdx.y is the frame; C2 is the frame's second queue (what the table kernel declines)
+template <int EXP, int ERF>
+__global__ __launch_bounds__(1024) void render_table_batch_kernel(const FrameArgs *__restrict__ frames)
+{
+    const FrameArgs &a = frames[blockIdx.y];
+    render_table_body<EXP, ERF>(a.S, a.T, a.C, a.R, a.O);
+}
+
+// The table kernel's error bound is that of the Abramowitz-Stegun erf (its kink) or of a smoother one (libm); the Exp must
+// be an accurate one (Exp(a)Exp(b) = Exp(a + b)): four pairs are instantiated, the host keeps every other pair exact.
+#define VRT_DISPATCH_TABLE(FN, ...)                                                                \
+    switch (exp_kind * 8 + erf_kind) {                                                             \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM>(__VA_ARGS__); break;      \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS>(__VA_ARGS__); break;          \
+    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM>(__VA_ARGS__); break;        \
+    default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
+    }
+template <int EXP, int ERF>
+static void launch_render_table_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                                  const RenderTarget &o, uint32_t grid, hipStream_t st)
+{
+    if (grid == 0) return;
+    hipLaunchKernelGGL((render_table_kernel<EXP, ERF>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
+}
+void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
+                         const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+{
+    VRT_DISPATCH_TABLE(launch_render_table_t, s, t, c, r, o, grid, st);
+}
+template <int EXP, int ERF>
+static void launch_render_table_only_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, hipStream_t st)
+{
+    if (nframes && grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF>), dim3(grid, nframes), dim3(1024), 0, st, d_frames);
+}
+void launch_render_table_only_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+{
+    VRT_DISPATCH_TABLE(launch_render_table_only_batch_t, d_frames, nframes, grid, st);
+}
+
+} // namespace vrtk

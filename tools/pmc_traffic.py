@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernel_source_sha():
     """Same identity bench.py computes: the summary is only used with the kernel sources it was taken with."""
     h = hashlib.sha256()
-    for name in ("vrt_kernels.hip", "vrt_kernels.h", "vrt_device_math.h"):
+    for name in ("vrt_kernels_common.hpp", "vrt_block_kernel.hip", "vrt_table_kernel.hip", "vrt_kernels.hip", "vrt_kernels.h",
+                 "vrt_device_math.h"):
         with open(os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
