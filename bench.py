@@ -148,6 +148,42 @@ def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
     }
 
 
+def parity_check(scene_mod, g, w, h, tiles_n, rad, npix, seed, cull_eps, cull_prune, table_budget, dense_blocks):
+    """max |GPU - oracle| of the float radiance on `npix` seeded LIT pixels of the frame the timed loop renders (the oracle as the
+    checker, after the timed region), with the a-priori bound of what the timed settings may cost beside it:
+    every dropped Gaussian changes a ray by less than 3 x its sigma*mag*exp(-x); tile level 3 eps N (N <= 4096: eps shrinks with N
+    beyond), the three lower levels 3 x 1365 eps each, the budgeted prune 3 kappa 1365 eps -- or, for a ray of a dense block, the table
+    kernel's budget instead of ray level + prune.  The bound is on the deviation from the reference's full sum; the oracle differs
+    from that by fp32 re-association only (a few 1e-6)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    O.build()
+    cam, _ = O.cli_camera(w, h)
+    og = g.view(O.GAUSSIAN)
+    tiles = O.tile_gaussians(2.0 / tiles_n, 2.0 / tiles_n, og, O.camera_view(cam))
+    rad = rad.reshape(-1, 4)
+    lum = rad[:, :3].sum(1)
+    lit = np.flatnonzero(lum > 0.05 * lum.max())
+    rng = np.random.default_rng(seed)
+    pix = np.sort(rng.choice(lit, min(npix, lit.size), replace=False)).astype(np.uint32)
+    t0 = time.perf_counter()
+    orad = O.render(w, h, O.camera_plane(cam), cam.position[:], og, tiles, pixels=pix, want_image=False, threads=host_threads())[1]
+    dt = time.perf_counter() - t0
+    ref_n = 4096.0 / 3.0
+    n = len(g)
+    levels = 3.0 * cull_eps * min(n, 4096) + 3 * 3.0 * ref_n * cull_eps
+    prune = 3.0 * cull_prune * ref_n * cull_eps
+    bound_block = levels + prune
+    bound_dense = 3.0 * cull_eps * min(n, 4096) + 2 * 3.0 * ref_n * cull_eps + table_budget
+    return {"pixels": int(pix.size), "pixel_choice": f"seeded ({seed}) among the {lit.size} pixels above 5 % of the peak luminance",
+            "max_abs": float(np.abs(rad[pix] - orad).max()), "bound": max(bound_block, bound_dense if dense_blocks else 0.0),
+            "bound_terms": {"tile_cell_block_ray_levels": levels, "budgeted_prune": prune,
+                            "dense_blocks_table_budget_instead_of_ray_level_and_prune": bound_dense if dense_blocks else None},
+            "tolerance": 1e-4, "oracle_peak_radiance": float(orad[:, :3].max()), "oracle_seconds": dt,
+            "settings": "the timed loop's (cull_eps, ray-level prune, table kernel as configured)"}
+
+
 def gather_batch_frames(gather_frames, steps):
     """Frames per RCCL gather for a run of `steps` timed steps: --gather-frames, but never more than a quarter of the run."""
     return max(1, min(int(gather_frames), max(int(steps), 1) // 4 if steps >= 4 else 1))
@@ -199,6 +235,8 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--tiles", type=int, default=16)
     ap.add_argument("--cull-eps", type=float, default=1e-9)
+    ap.add_argument("--table-step", type=float, default=0.05, help="node spacing of the table kernel (library default 0.05; 0 = exact kernels only)")
+    ap.add_argument("--parity-pixels", type=int, default=256, help="lit pixels the oracle checks after the timed region (N = 1; with --no-cpu-baseline: none)")
     ap.add_argument("--cull-prune", type=float, default=6.0, help="budget factor of the block kernel's ray-level prune (library default 6; 0 = off)")
     ap.add_argument("--gather-frames", type=int, default=32, help="N > 1: frames per RCCL gather (one collective per batch)")
     ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
@@ -274,6 +312,7 @@ def main():
             r_.set_camera_view(w, h, view)   # in-kernel rays = the reference's plane points, bit for bit (camera.cpp:60-69)
         r_.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
         r_.set_cull_prune(args.cull_prune)
+        r_.set_table_step(args.table_step)
         r_.set_shard(*((0, 1) if solo else (rank, world)))
         return r_
 
@@ -362,7 +401,9 @@ def main():
             def render_shard_batch(b, nf):
                 if fg.sent[b] is not None:
                     rstreams[b].wait_event(fg.sent[b])     # the previous batch in this buffer has been copied out
+                r0 = fg.mark(rstreams[b])
                 batch_calls[b](batch_ptrs[b], rstreams[b].cuda_stream, nf)
+                fg.note("render", r0, fg.mark(rstreams[b]))
                 done = torch.cuda.Event()
                 done.record(rstreams[b])
                 torch.cuda.current_stream().wait_event(done)
@@ -511,6 +552,51 @@ def main():
         barrier()
         retained_serial_ms = (time.perf_counter() - t2) / n_serial * 1e3
         sweep["retained_frame_buffers"] = {"frames_in_flight": nctx, "ms_per_step": retained_ms, "serial_ms_per_frame": retained_serial_ms}
+    # What the speed costs in accuracy (round-3 verdict): the same loop at EXACT settings -- no budgeted prune, table kernel off
+    # (cull_eps stays: its thresholds' share is <= 2.5e-6) -- in flight and serial, after the timed region.
+    exact = None
+    if solo and world == 1 and not args.plane_arrays:
+        for r_ in ctxs:
+            r_.set_cull_prune(0.0)
+            r_.set_table_step(0.0)
+        run(8 * nctx)
+        barrier()
+        t2 = time.perf_counter()
+        run(n_serial)
+        barrier()
+        ex_ms = (time.perf_counter() - t2) / n_serial * 1e3
+        t2 = time.perf_counter()
+        run(n_serial, 1, serial=True)
+        barrier()
+        ex_serial_ms = (time.perf_counter() - t2) / n_serial * 1e3
+        _, ex_rad = r.render(origin, pack)
+        exact = {"what": "--cull-prune 0 and the table kernel off (vrt_hip_set_table_step(0)); level-wise cull thresholds as timed",
+                 "frames_in_flight": nctx, "ms_per_step": ex_ms, "value": w * h / (ex_ms * 1e-3) / 1e6,
+                 "ms_per_frame": ex_serial_ms, "serial_value": w * h / (ex_serial_ms * 1e-3) / 1e6, "steps": n_serial}
+        for r_ in ctxs:
+            r_.set_cull_prune(args.cull_prune)
+            r_.set_table_step(args.table_step)
+        run(4 * nctx)
+        barrier()
+    # N > 1: where a rank's time goes -- the timed loop once more with the gatherer's phase timers on (sharding.py: "render" on the
+    # batch's render stream, "gather" from enqueue until the frame stream may use it, "assemble" on rank 0), all ranks to rank 0
+    per_rank = None
+    if not solo:
+        fg.timing = True
+        fg.phase_ms()
+        run(args.steps)
+        barrier()
+        ph = fg.phase_ms()
+        fg.timing = False
+        nfr = max(1, ph.get("frames", 0))
+        mine = torch.tensor([rank, ph.get("render", 0.0) / nfr, ph.get("gather", 0.0) / nfr, ph.get("gather_nccl", -nfr) / nfr,
+                             ph.get("assemble", 0.0) / nfr, ph.get("host_in_run", 0.0) / nfr, float(ph.get("batches_gathered_twice", 0))],
+                            dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": int(v[0]), "render_ms_per_frame": float(v[1]), "gather_ms_per_frame_upper_bound": float(v[2]),
+                     "gather_collective_ms_per_frame": (float(v[3]) if float(v[3]) >= 0 else None), "assemble_ms_per_frame": float(v[4]),
+                     "host_ms_per_frame_in_loop": float(v[5]), "batches_gathered_twice": int(v[6])} for v in (t_.cpu().tolist() for t_ in allr)]
     r.enable_kernel_timing(1)
     run(max(50, min(args.steps, 100)), 1, serial=True)
     barrier()
@@ -537,7 +623,7 @@ def main():
         n_entries = int(counts.sum())
         r.enable_stats(True)
         r.set_shard(0, 1)
-        _img, _ = r.render(origin, pack, want_radiance=False)
+        _img, _rad = r.render(origin, pack)
         # the gathered + assembled frame of the timed loop must be the single-GPU frame, bit for bit
         bad = [(i_, int((im.cpu().numpy().view(np.uint32) != _img.reshape(-1)).sum())) for i_, im in enumerate(images)]
         bad = [b_ for b_ in bad if b_[1]]
@@ -651,6 +737,12 @@ def main():
                                  "in flight a launch shares the GPU with the other contexts' kernels and lasts longer "
                                  "(kernel_ms_with_frames_in_flight); kernel_ms is the serial launch, a component of ms_per_frame"},
             # the same loop with one context: frame k+1 starts when frame k is done
+            # the same loop at exact settings, and what the timed settings deviate by (checked by the oracle below: "parity")
+            "exact_settings": exact,
+            "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "per_rank": per_rank,
+                            "per_rank_note": "a repeat of the timed loop with phase timers on (after the timed region); gather = from enqueue "
+                                             "until the frame stream may use the result (upper bound of the collective; its own duration "
+                                             "where TORCH_NCCL_ENABLE_TIMING=1 makes the backend keep it)"} if world > 1 else None),
             "serial": {"frames_in_flight": 1, "ms_per_step": serial_ms, "value": w * h / (serial_ms * 1e-3) / 1e6, "steps": n_serial},
             "moving_camera": moving,
             "in_flight_sweep_ms_per_step": sweep,   # frames in flight -> ms per step; + the retained-buffer variant of the loop
@@ -660,6 +752,12 @@ def main():
                      "dense_overflow_blocks": st["overflow_blocks"]},
         }
         if not args.no_cpu_baseline and world == 1:
+            # the oracle as the CHECKER of the frame the timed loop renders (after the timed region), then as the CPU baseline
+            if args.parity_pixels > 0 and not args.plane_arrays:
+                result["parity"] = parity_check(scene, g, w, h, args.tiles, _rad, args.parity_pixels, 2048 + args.grid, args.cull_eps,
+                                                args.cull_prune, 2.5e-5, st["dense_blocks"] > 0)
+                if exact is not None:
+                    result["parity"]["timed_vs_exact_settings_max_abs"] = float(np.abs(_rad - ex_rad).max())
             result["cpu_baseline"] = cpu_baseline(scene, g, w, h, args.tiles, args.grid, "")
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))

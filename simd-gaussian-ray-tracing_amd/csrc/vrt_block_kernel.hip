@@ -135,115 +135,6 @@ __device__ __forceinline__ void shade_lanes_balanced(const float4 *s_A, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// (ray, emitter) PAIRS as lanes (round 3).  shade_chunk above gives every lane its ray and runs up to six of the ray's
-// emitters side by side: all lanes loop to the block's longest list, so a ray with 3 entries beside one with 6 idles through
-// half of the emitter slots AND half of the absorber iterations (64 % useful lanes on `-g 64 -w 2048`).  Here the emitters of all
-// 64 rays are packed densely: pair p = (ray, e-th entry of its list), lane = pair, NPASS = ceil(pairs / 64) passes held side
-// by side in registers.  Per absorber slot j every lane first computes, AS A RAY, its j-th absorber's (A, m, E, r) -- once per
-// (ray, absorber), as before -- and puts them into a 1-KB LDS row, from which each pass fetches the values of its pair's ray with
-// one 16-byte read (by ds_bpermute, four per pass and slot, the LDS instructions ate the gain: VALU -11 %, wave cycles +2 %); then
-// the five terms of the pair.  Emitter slots are no longer padded; absorber slots still are (a pair whose ray has no j-th absorber
-// adds A = 0).  The inner sums go through LDS back to the ray's lane, which adds them in list order.
-// LDS: the tail of s_lane (lists are at most PAIR_PL = 8 long on this path): pair -> ray map, the rays' first pair, the inner sums.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t PAIR_PL = 8, PAIR_NPASS_MAX = 6;
-static_assert(PL * 64 >= PAIR_PL * 64 + 512 + 256 + PAIR_NPASS_MAX * 64 * 4, "s_lane holds the pair path's scratch behind the lists");
-template <int EXP, int ERF, int NPASS>
-__device__ __forceinline__ void shade_pairs(const float4 *s_A, const float4 *s_B, const float4 *s_M, const float4 *s_C, const float *s_q,
-                                            float4 *s_pre /* [2][64] */, uint8_t *s_lane, uint32_t nl, uint32_t nmax, uint32_t first_pair, uint32_t n_pairs, uint32_t lane,
-                                            const LaneRay &ray, float &Lr, float &Lg, float &Lb, float &La)
-{
-    const ErfEval<ERF> erf;
-    uint8_t *s_map = s_lane + PAIR_PL * 64;                                   // [<= 384] ray of pair p
-    uint32_t *s_first = reinterpret_cast<uint32_t *>(s_lane + PAIR_PL * 64 + 512);  // [64] first pair of ray l
-    float *s_inner = reinterpret_cast<float *>(s_lane + PAIR_PL * 64 + 512 + 256);  // [<= 384] inner sum of pair p
-    for (uint32_t e = 0; e < nmax; ++e)
-        if (e < nl) s_map[first_pair + e] = (uint8_t)lane;
-    s_first[lane] = first_pair;
-    __syncthreads();
-    // the pairs of this lane, one per pass
-    uint32_t p_ray[NPASS], p_li[NPASS];
-    float e_mubar[NPASS], e_sigma[NPASS], acc[NPASS][5];
-#pragma unroll
-    for (int q = 0; q < NPASS; ++q) {
-        const uint32_t p = (uint32_t)q * 64u + lane;
-        const bool vp = p < n_pairs;
-        p_ray[q] = vp ? s_map[p] : 0u;
-        const uint32_t e = vp ? p - s_first[p_ray[q]] : 0u;
-        p_li[q] = vp ? s_lane[e * 64 + p_ray[q]] : 0u;
-        const float nx = __shfl(ray.nx, (int)p_ray[q], 64), ny = __shfl(ray.ny, (int)p_ray[q], 64), nz = __shfl(ray.nz, (int)p_ray[q], 64);
-        const float4 a = s_A[p_li[q]];
-        e_mubar[q] = dot3_ref(a.x, a.y, a.z, nx, ny, nz);
-        e_sigma[q] = s_M[p_li[q]].w;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) acc[q][k] = 0.f;
-    }
-    // absorber slots.  The rays' values of slot j + 1 are computed while the passes work on slot j (two rows of LDS; one
-    // wavefront: its LDS instructions execute in order, so a row written before it is read needs no barrier, only the
-    // compiler kept from reordering the two)
-    auto ray_values = [&](uint32_t j) {
-        const bool vj = j < nl;
-        const uint32_t lj = vj ? s_lane[j * 64 + lane] : 0u;
-        const float4 ca = s_A[lj], cb = s_B[lj];
-        const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
-        const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
-        const float A = vj ? cb.z * vexp<EXP>(-(d2 * cb.y)) : 0.f;
-        const float m = mubar * cb.x;
-        return make_float4(A, m, erf(-m), cb.x);
-    };
-    s_pre[lane] = ray_values(0);
-    for (uint32_t j = 0; j < nmax; ++j) {
-        __builtin_amdgcn_wave_barrier();
-        const float4 *row = s_pre + (j & 1u) * 64u;
-        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j + 1 < nmax) nxt = ray_values(j + 1);
-#pragma unroll
-        for (int q = 0; q < NPASS; ++q) {
-            const float4 v = row[p_ray[q]];
-            const float base = __builtin_fmaf(e_mubar[q], v.w, -v.y);
-            const float step = e_sigma[q] * v.w;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) acc[q][k] = __builtin_fmaf(v.x, v.z - erf(__builtin_fmaf((float)(k - 4), step, base)), acc[q][k]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (j + 1 < nmax) s_pre[((j + 1) & 1u) * 64u + lane] = nxt;
-    }
-    // emission (see shade_list), per pair
-#pragma unroll
-    for (int q = 0; q < NPASS; ++q) {
-        const uint32_t p = (uint32_t)q * 64u + lane;
-        const float nx = __shfl(ray.nx, (int)p_ray[q], 64), ny = __shfl(ray.ny, (int)p_ray[q], 64), nz = __shfl(ray.nz, (int)p_ray[q], 64);
-        const float4 ms = s_M[p_li[q]];
-        const float inv2s2 = s_B[p_li[q]].y;
-        const float qq = s_q[p_li[q]];
-        float inner = 0.f;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[q]);
-            const float px = sub_ref(madd_ref(nx, sk, ray.ox), ms.x);
-            const float py = sub_ref(madd_ref(ny, sk, ray.oy), ms.y);
-            const float pz = sub_ref(madd_ref(nz, sk, ray.oz), ms.z);
-            const float dd = dot3_ref(px, py, pz, px, py, pz);
-            inner += emission_term<EXP>(qq, dd * inv2s2, acc[q][k]);
-        }
-        if (p < n_pairs) s_inner[p] = inner;
-    }
-    __syncthreads();
-    // back on the ray's lane: its emitters in list order
-    Lr = Lg = Lb = La = 0.f;
-    for (uint32_t e = 0; e < nmax; ++e) {
-        if (e < nl) {
-            const float inner = s_inner[first_pair + e];
-            const float4 alb = s_C[s_lane[e * 64 + lane]];
-            Lr = __builtin_fmaf(alb.x, inner, Lr);
-            Lg = __builtin_fmaf(alb.y, inner, Lg);
-            Lb = __builtin_fmaf(alb.z, inner, Lb);
-            La = __builtin_fmaf(alb.w, inner, La);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Image kernel: persistent one-wave workgroups; a work item is one 8x8 pixel block (64 rays, lane = ray) of a
 // 32x32 pixel cell with a non-empty candidate list.  A wave's first block is static (item = wave); frames with
 // more blocks than waves hand the rest out through eight work counters (CellGrid::rq).  Empty cells are cleared
@@ -255,19 +146,6 @@ __device__ __forceinline__ void shade_pairs(const float4 *s_A, const float4 *s_B
 #else
 #define VRT_RENDER_ATTR
 #endif
-
-// exactly `size` emitters (list positions i0 .. i0+size-1 of every lane), size 0..4
-template <int EXP, int ERF>
-__device__ __forceinline__ void shade_range(const float4 *s_A, const float4 *s_B, const float4 *s_M, const float4 *s_C,
-                                            const float *s_q, const uint8_t *s_lane, uint32_t nl, uint32_t nmax, uint32_t lane,
-                                            const LaneRay &ray, uint32_t i0, uint32_t size, float &Lr, float &Lg, float &Lb, float &La)
-{
-    Lr = Lg = Lb = La = 0.f;
-    if (size == 4) shade_chunk<EXP, ERF, 4>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
-    else if (size == 3) shade_chunk<EXP, ERF, 3>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
-    else if (size == 2) shade_chunk<EXP, ERF, 2>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
-    else if (size == 1) shade_chunk<EXP, ERF, 1>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, i0, Lr, Lg, Lb, La);
-}
 
 // Budgeted ray-level cull (round 3).  The level-wise thresholds above are worst-case counting: a level that n candidates enter drops
 // below eps * 1365 / n, as if all n sat just under it.  A ray's own list knows better: what it lost is the SUM of sigma*mag*exp(-x) over
@@ -308,13 +186,10 @@ __device__ __forceinline__ uint32_t prune_list(const __half *s_t, uint8_t *s_lan
     return w;
 }
 
-// NW = waves per block.  NW = 1: one wavefront shades a block on its own.  NW = 2: the two waves of a workgroup hold the
-// same 64 rays, share ONE block cull and ONE set of per-ray lists through LDS and take half of the emitters each; their
-// partial radiances are added in wave order.  A frame of `-g 64 -w 2048` is ~2500 equally heavy blocks for 1024 SIMDs,
-// three resident waves each: with whole blocks as the unit half of the SIMDs carry three heavy blocks and the rest two
-// (27 us against a balanced 21 us, VRT_HIP_TIMELINE); with half blocks pulled from the work queues the unit is half
-// as long and the per-SIMD sums even out.
-template <int EXP, int ERF, int EC, int NW, bool CLAIM = false>
+// One wavefront shades a block on its own.  (Rounds 1-3 carried a two-waves-per-block variant -- shared cull and lists, half of the
+// emitters each -- measured slower every time, profiles/r02_experiments.md: the cull and list phases are latency-bound and do not
+// shrink when a block gets two waves.  Retired in round 4.)
+template <int EXP, int ERF, int EC, bool CLAIM = false>
 __device__ __forceinline__ void render_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R, const RenderTarget &O)
 {
     // every row a kept candidate needs later (absorber: A, B; emitter: mu/sigma, albedo, sigma*mag) is fetched in the one
@@ -322,13 +197,8 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     __shared__ float4 s_A[PCAP], s_B[PCAP], s_M[PCAP], s_C[PCAP];
     __shared__ float s_q[PCAP];
     __shared__ uint8_t s_lane[PL * 64];
-    __shared__ __half s_t[NW == 1 ? PRUNE_PL * 64 : 1]; // ln(sigma*mag*exp(-x) / eps) of the first PRUNE_PL entries of every lane's list (prune_list)
-#ifdef VRT_PAIR_LANES
-    __shared__ float4 s_pre[NW == 1 ? 128 : 1]; // pair lanes: the rays' (A, m, E, r) of the current and the next absorber slot
-#endif
-    __shared__ float4 s_L[NW > 1 ? 64 : 1];
-    __shared__ uint32_t s_cnt[2], s_item;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wave = blockIdx.x, G = gridDim.x;
+    __shared__ __half s_t[PRUNE_PL * 64]; // ln(sigma*mag*exp(-x) / eps) of the first PRUNE_PL entries of every lane's list (prune_list)
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x, G = gridDim.x;
     const bool first = threadIdx.x == 0;
     const uint64_t npix = (uint64_t)R.width * R.height;
     // A block's way to its candidates is a chain of dependent loads (queue entry -> list -> parameter rows), and at the start of a launch
@@ -351,7 +221,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     // ---- clear the cells nothing can reach (4 B per ray: the only HBM traffic of most of the frame) ----
     const uint32_t zero_px = (O.pack_flags & VRT_ALPHA_COMPUTED) ? 0u : 0xFF000000u;
     // (only when the list kernel of this frame did not do it: unfused lists, or a re-render from unchanged lists)
-    for (uint32_t cell = wave; cell < C.n_cells && !O.cleared && wv == 0; cell += G) { // one whole cell per item: 16 x (2 rows of 32 px)
+    for (uint32_t cell = wave; cell < C.n_cells && !O.cleared; cell += G) { // one whole cell per item: 16 x (2 rows of 32 px)
         if (C.count[cell] != 0u) continue;
         const uint32_t cpt = C.cells_x * C.cells_y;
         const uint32_t lt = cell / cpt, ci = cell % cpt;
@@ -374,47 +244,26 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     if (wave == 0 && threadIdx.x < RQ_N) C.rq_next[threadIdx.x * RQ_STRIDE] = 0;
     const uint32_t n_dyn = n_shade > G ? n_shade - G : 0u;
     static_assert(RQ_N <= 64, "one bit of rq_dead and one lane of the poll per queue");
-    uint32_t rq_tries = 0;
     uint64_t rq_dead = 0; // queues this wave has seen run out (bit l = the l-th from its own; RQ_N = 64 of them: 64 bits)
     // next block: blocks cost between ~1 and ~30 units (the pair loops are quadratic in the per-ray list length), so
     // after its static first block a workgroup pulls more from the queues, its own first, until all are empty
     auto next_item = [&]() -> uint32_t {
-        if constexpr (NW == 1) {
-            // all RQ_N counters are looked at in ONE round trip (lane l reads the l-th queue from the wave's own on): a wave that is done
-            // leaves after one load instead of after RQ_N dependent ones -- at the end of a launch that was 5 us of every wave's exit
-            while (true) {
-                const uint32_t q = (wave + lane) % RQ_N;
-                const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
-                bool have = false;
-                if (lane < RQ_N && per && !((rq_dead >> lane) & 1ull)) have = __hip_atomic_load(C.rq + q * RQ_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per;
-                const unsigned long long mask = __ballot(have);
-                if (!mask) return 0xFFFFFFFFu;
-                const uint32_t l = (uint32_t)__builtin_ctzll(mask);
-                const uint32_t ql = (wave + l) % RQ_N, perl = (n_dyn - ql + RQ_N - 1) / RQ_N;
-                uint32_t m = 0xFFFFFFFFu;
-                if (first) m = atomicAdd(C.rq + ql * RQ_STRIDE, 1u);
-                m = __builtin_amdgcn_readfirstlane(m);
-                if (m < perl) return G + ql + RQ_N * m;
-                rq_dead |= 1ull << l; // lost the race for its last entry: that queue is empty for good, so at most RQ_N rounds
-            }
-        } else {
-            while (rq_tries < RQ_N) {
-                const uint32_t q = (wave + rq_tries) % RQ_N;
-                const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
-                uint32_t m = 0xFFFFFFFFu;
-                if (first && per) {
-                    uint32_t *ctr = C.rq + q * RQ_STRIDE;
-                    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) m = atomicAdd(ctr, 1u);
-                }
-                // both waves take the same item: through LDS
-                if (first) s_item = m;
-                __syncthreads();
-                m = s_item;
-                __syncthreads();
-                if (m < per) return G + q + RQ_N * m;
-                ++rq_tries;
-            }
-            return 0xFFFFFFFFu;
+        // all RQ_N counters are looked at in ONE round trip (lane l reads the l-th queue from the wave's own on): a wave that is done
+        // leaves after one load instead of after RQ_N dependent ones -- at the end of a launch that was 5 us of every wave's exit
+        while (true) {
+            const uint32_t q = (wave + lane) % RQ_N;
+            const uint32_t per = n_dyn > q ? (n_dyn - q + RQ_N - 1) / RQ_N : 0u;
+            bool have = false;
+            if (lane < RQ_N && per && !((rq_dead >> lane) & 1ull)) have = __hip_atomic_load(C.rq + q * RQ_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per;
+            const unsigned long long mask = __ballot(have);
+            if (!mask) return 0xFFFFFFFFu;
+            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+            const uint32_t ql = (wave + l) % RQ_N, perl = (n_dyn - ql + RQ_N - 1) / RQ_N;
+            uint32_t m = 0xFFFFFFFFu;
+            if (first) m = atomicAdd(C.rq + ql * RQ_STRIDE, 1u);
+            m = __builtin_amdgcn_readfirstlane(m);
+            if (m < perl) return G + ql + RQ_N * m;
+            rq_dead |= 1ull << l; // lost the race for its last entry: that queue is empty for good, so at most RQ_N rounds
         }
     };
     auto write_block = [&](float Lr, float Lg, float Lb, float La, bool valid, uint64_t out) {
@@ -434,7 +283,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     uint32_t claim = 0xFFFFFFFFu;
     bool claimed = false;
     auto advance = [&]() -> uint32_t {
-        if constexpr (NW == 1 && CLAIM) {
+        if constexpr (CLAIM) {
             if (claimed) {
                 claimed = false;
                 const uint32_t m = __builtin_amdgcn_readfirstlane(claim);
@@ -465,7 +314,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
         if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
 
-        LaneRay ray = pixel_ray(R, pix); // NW = 2: both waves hold the same 64 rays
+        LaneRay ray = pixel_ray(R, pix);
         // the origin is wave-uniform (SGPRs): as a VGPR operand the 15 adds per emitter of the emission issue at full rate
         ray.ox = pin_vgpr(ray.ox); ray.oy = pin_vgpr(ray.oy); ray.oz = pin_vgpr(ray.oz);
 
@@ -481,13 +330,12 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
         const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
 
-        // ---- block cull over the cell's list (ballot compaction, order preserving; NW = 2: 128 entries per pass, the
-        //      second wave's survivors behind the first's) ----
+        // ---- block cull over the cell's list (ballot compaction, order preserving) ----
         __syncthreads(); // previous item's LDS reads are done
         const float slack = level_slack(T.cull_ref_n, n_list);
         uint32_t cnt = 0;
-        for (uint32_t base = 0; base < n_list; base += 64 * NW) {
-            const uint32_t k = base + wv * 64 + lane;
+        for (uint32_t base = 0; base < n_list; base += 64) {
+            const uint32_t k = base + lane;
             bool keep = false;
             float4 a, bq, ms, alb;
             float q;
@@ -497,23 +345,14 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
                 keep = cone_keeps(cone, a, make_float4(bq.x, bq.y, bq.z, slack_cull_x(bq.w, slack, T.floor_x)));
             }
             const unsigned long long mask = __ballot(keep);
-            uint32_t before = 0, pass_total = (uint32_t)__popcll(mask);
-            if constexpr (NW == 2) {
-                if (lane == 0) s_cnt[wv] = pass_total;
-                __syncthreads();
-                before = wv ? s_cnt[0] : 0u;
-                pass_total = s_cnt[0] + s_cnt[1];
-            }
-            const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
             if (keep && pos < PCAP) { s_A[pos] = a; s_B[pos] = bq; s_M[pos] = ms; s_C[pos] = alb; s_q[pos] = q; }
-            cnt += pass_total;
-            if constexpr (NW == 2) __syncthreads(); // s_cnt is rewritten by the next pass
+            cnt += (uint32_t)__popcll(mask);
         }
         __syncthreads();
 
         const unsigned long long tl1 = O.timeline ? wall_clock64() : 0ull;
-        // ---- lane cull: this ray's own candidates (exact per-ray criterion x > cull_x, no margin needed).  NW = 2: both
-        //      waves count (each needs nl), the first one files the list ----
+        // ---- lane cull: this ray's own candidates (exact per-ray criterion x > cull_x, no margin needed) ----
         uint32_t nl = 0;
         bool fast = cnt <= PCAP;
         if (fast) {
@@ -523,12 +362,10 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
                 const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
                 const float x = sub_ref(a.w, mul_ref(mubar, mubar)) * bq.y;
                 if (!(x > slack_cull_x(bq.w, slack_r, T.floor_x))) {
-                    if (nl < PL && wv == 0) s_lane[nl * 64 + lane] = (uint8_t)j;
-                    if constexpr (NW == 1) {
-                        if (nl < PRUNE_PL) { // fp16 rounds to nearest within 2^-11: the bias keeps the stored value above the true one
-                            const float t = bq.w - x;
-                            s_t[nl * 64 + lane] = __float2half(bq.w < T.floor_x ? t + 0.001f * fabsf(t) + 1e-4f : INFINITY);
-                        }
+                    if (nl < PL) s_lane[nl * 64 + lane] = (uint8_t)j;
+                    if (nl < PRUNE_PL) { // fp16 rounds to nearest within 2^-11: the bias keeps the stored value above the true one
+                        const float t = bq.w - x;
+                        s_t[nl * 64 + lane] = __float2half(bq.w < T.floor_x ? t + 0.001f * fabsf(t) + 1e-4f : INFINITY);
                     }
                     ++nl;
                 }
@@ -553,27 +390,25 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         uint32_t nmax = nl;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
-        if constexpr (NW == 1) {
-            if (C.prune_budget > 0.f && nmax <= PRUNE_PL) {
-                switch (nmax) { // exactly as many entries as the block's longest list has, while that is cheap
-                case 0: break;
-                case 1: nl = prune_list<1>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 2: nl = prune_list<2>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 3: nl = prune_list<3>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 4: nl = prune_list<4>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 5: nl = prune_list<5>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 6: nl = prune_list<6>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 7: nl = prune_list<7>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 8: nl = prune_list<8>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                case 9: case 10: case 11: case 12: nl = prune_list<12>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                default: nl = prune_list<16>(s_t, s_lane, nl, lane, C.prune_budget); break;
-                }
-                nmax = nl;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+        if (C.prune_budget > 0.f && nmax <= PRUNE_PL) {
+            switch (nmax) { // exactly as many entries as the block's longest list has, while that is cheap
+            case 0: break;
+            case 1: nl = prune_list<1>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 2: nl = prune_list<2>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 3: nl = prune_list<3>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 4: nl = prune_list<4>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 5: nl = prune_list<5>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 6: nl = prune_list<6>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 7: nl = prune_list<7>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 8: nl = prune_list<8>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            case 9: case 10: case 11: case 12: nl = prune_list<12>(s_t, s_lane, nl, lane, C.prune_budget); break;
+            default: nl = prune_list<16>(s_t, s_lane, nl, lane, C.prune_budget); break;
             }
+            nmax = nl;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
         }
-        if (O.stats && wv == 0) {
+        if (O.stats) {
             unsigned long long tot = nl;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor((int)tot, off, 64);
@@ -583,57 +418,16 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             if (lane == 0) { atomicAdd(&O.stats[3], tot); atomicAdd(&O.stats[4], (unsigned long long)nmax); atomicAdd(&O.stats[12], sq); }
         }
         const unsigned long long tl2 = O.timeline ? wall_clock64() : 0ull;
-        if constexpr (NW == 1 && CLAIM) {
+        if constexpr (CLAIM) {
             if (claim_early && !(rq_dead & 1ull)) {
                 claimed = true;
                 if (first) claim = atomicAdd(C.rq + q_own * RQ_STRIDE, 1u);
             }
         }
         float Lr, Lg, Lb, La;
-        if constexpr (NW == 1) {
-#ifdef VRT_PAIR_LANES // experiment (profiles/r03_experiments.md): make LANES='-DVRT_RENDER_ECMAX=6 -DVRT_RENDER_WPE=3 -DVRT_PAIR_LANES', VRT_HIP_PAIR_LANES=1|2
-            // short lists (sparse scenes): (ray, emitter) pairs as lanes; a function of the block alone (its list lengths)
-            uint32_t incl = nl;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-                if (lane >= (uint32_t)off) incl += up;
-            }
-            const uint32_t n_pairs = (uint32_t)__shfl((int)incl, 63, 64), npass = (n_pairs + 63u) / 64u;
-            // instruction counts of the two layouts for this block (per lane; absorber set-up 30-35, five terms 60-66, an emission 160):
-            // ray per lane -- balanced chunks of at most 6 emitters, every chunk walks all nmax absorber slots; pairs -- npass passes
-            const uint32_t chunks = (nmax + VRT_RENDER_ECMAX - 1) / VRT_RENDER_ECMAX;
-            const uint32_t cost_rays = nmax * (30u * chunks + 60u * nmax) + 160u * nmax;
-            const uint32_t cost_pairs = nmax * (35u + 66u * npass) + 160u * npass + 150u;
-            if (C.pair_lanes && nmax <= PAIR_PL && npass >= 1u && npass <= PAIR_NPASS_MAX && (C.pair_lanes > 1 || cost_pairs * 20u < cost_rays * 19u)) {
-                switch (npass) {
-                case 1: shade_pairs<EXP, ERF, 1>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
-                case 2: shade_pairs<EXP, ERF, 2>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
-                case 3: shade_pairs<EXP, ERF, 3>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
-                case 4: shade_pairs<EXP, ERF, 4>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
-                case 5: shade_pairs<EXP, ERF, 5>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
-                default: shade_pairs<EXP, ERF, 6>(s_A, s_B, s_M, s_C, s_q, s_pre, s_lane, nl, nmax, incl - nl, n_pairs, lane, ray, Lr, Lg, Lb, La); break;
-                }
-            } else
-#endif
-            if constexpr (VRT_RENDER_ECMAX > 4) shade_lanes_balanced<EXP, ERF, VRT_RENDER_ECMAX>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
-            else shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
-            write_block(Lr, Lg, Lb, La, valid, out);
-        } else {
-            // emitters: up to 2*EC of them are cut in two halves, one chunk per wave; longer lists alternate chunks of EC
-            if (nmax <= 2u * EC) {
-                const uint32_t h = (nmax + 1) / 2;
-                shade_range<EXP, ERF>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, wv ? h : 0u, wv ? nmax - h : h, Lr, Lg, Lb, La);
-            } else {
-                shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La, wv * EC, 2 * EC);
-            }
-            if (wv == 1) s_L[lane] = make_float4(Lr, Lg, Lb, La);
-            __syncthreads();
-            if (wv == 0) {
-                const float4 o2 = s_L[lane];
-                write_block(Lr + o2.x, Lg + o2.y, Lb + o2.z, La + o2.w, valid, out);
-            }
-        }
+        if constexpr (VRT_RENDER_ECMAX > 4) shade_lanes_balanced<EXP, ERF, VRT_RENDER_ECMAX>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+        else shade_lanes<EXP, ERF, EC>(s_A, s_B, s_M, s_C, s_q, s_lane, nl, nmax, lane, ray, Lr, Lg, Lb, La);
+        write_block(Lr, Lg, Lb, La, valid, out);
         if (O.timeline && first) {
             unsigned long long *tl = O.timeline + 5 * (size_t)item;
             tl[0] = tl0; tl[1] = tl1; tl[2] = tl2; tl[3] = wall_clock64();
@@ -644,28 +438,27 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
     }
 }
 
-template <int EXP, int ERF, int EC, int NW, bool CLAIM = false>
-__global__ __launch_bounds__(64 * NW) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+template <int EXP, int ERF, int EC, bool CLAIM = false>
+__global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
 {
-    render_body<EXP, ERF, EC, NW, CLAIM>(S, T, C, R, O);
+    render_body<EXP, ERF, EC, CLAIM>(S, T, C, R, O);
 }
 // several frames per launch: blockIdx.y is the frame (FrameArgs)
 template <int EXP, int ERF, int EC, bool CLAIM = false>
 __global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_batch_kernel(const FrameArgs *__restrict__ frames)
 {
     const FrameArgs &a = frames[blockIdx.y];
-    render_body<EXP, ERF, EC, 1, CLAIM>(a.S, a.T, a.C, a.R, a.O);
+    render_body<EXP, ERF, EC, CLAIM>(a.S, a.T, a.C, a.R, a.O);
 }
 
 template <int EXP, int ERF>
 static void launch_render_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
-                            const RenderTarget &o, uint32_t grid, int nw, hipStream_t st)
+                            const RenderTarget &o, uint32_t grid, hipStream_t st)
 {
     if (grid == 0) return;
-    if (nw == 2) hipLaunchKernelGGL((render_kernel<EXP, ERF, 4, 2>), dim3(grid), dim3(128), 0, st, s, t, c, r, o);
-    else if (c.claim_early > 0 && EXP == VRT_EXP_VCL && ERF == VRT_ERF_AS) // frames with many more blocks than waves (the default pair only: compile time)
-        hipLaunchKernelGGL((render_kernel<VRT_EXP_VCL, VRT_ERF_AS, 4, 1, true>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
-    else hipLaunchKernelGGL((render_kernel<EXP, ERF, 4, 1>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
+    if (c.claim_early > 0 && EXP == VRT_EXP_VCL && ERF == VRT_ERF_AS) // frames with many more blocks than waves (the default pair only: compile time)
+        hipLaunchKernelGGL((render_kernel<VRT_EXP_VCL, VRT_ERF_AS, 4, true>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
+    else hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
 }
 
 template <int EXP, int ERF>
@@ -678,9 +471,9 @@ static void launch_render_batch_t(const FrameArgs *d_frames, uint32_t nframes, u
 
 
 void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r, const RenderTarget &o,
-                   uint32_t grid, int nw, int exp_kind, int erf_kind, hipStream_t st)
+                   uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
-    VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, nw, st);
+    VRT_DISPATCH_EXP_ERF(launch_render_t, s, t, c, r, o, grid, st);
 }
 void launch_render_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, bool claim, int exp_kind, int erf_kind, hipStream_t st)
 {

@@ -102,19 +102,16 @@ struct vrt_hip_ctx {
     };
     std::vector<Retained> retained; // one history per frame buffer (at most MAX_ASSEMBLY_FRAMES, oldest dropped)
     // tile cones of the list kernel: a function of the rays and the tile geometry only, kept across frames (cone_key =
-    // what they were made for; VRT_HIP_TILE_CONES=0: every workgroup builds its own, as before)
+    // what they were made for)
     DevBuf<float4> tile_cones;
     uint32_t cone_gen = 0;     // tag of the rows made for cone_key's camera (BinArgs::cone_gen)
     std::string cone_key;
     uint32_t plane_gen = 0;
-    bool cache_cones = true;
-    // cells with at most this many candidates are shaded last (CellGrid::light_threshold; VRT_HIP_LIGHT_CELLS, 0 = off);
+    // cells with at most this many candidates are shaded last (CellGrid::light_threshold; 32 and more file too many cells as light, profiles/r02_experiments.md);
     // lists_light: what the lists now in the buffers were built with (0 for sparse shards and the two-kernel list path)
-    uint32_t light_cells = 24, lists_light = 0;
+    static constexpr uint32_t light_cells = 24;
+    uint32_t lists_light = 0;
     int claim_early = 8;         // CellGrid::claim_early (measured: 2 leaves `-g 16 -w 2048` at 67 us, 8 takes it to 43, "always" costs a 12-waves-per-CU grid 8 % in flight); VRT_HIP_CLAIM_EARLY=0: the block kernel's waves ask for their next block only when they are done with the current one
-    int pair_lanes = 0;          // VRT_HIP_PAIR_LANES: 0 (default) the block kernel shades every block ray per lane; 1: (ray, emitter) pairs as
-                                 // lanes where an instruction-count model says they are cheaper; 2: wherever they fit.  Measured: -10 % VALU
-                                 // instructions, -1 % time (profiles/r03_experiments.md): off
     bool skip_idle_dense = true; // VRT_HIP_DENSE_SKIP=0: the dense kernel is launched behind every block kernel
     float albedo_scale = 1.f;    // max(1, largest |albedo| of the scene): divides the prune budget
     float cull_prune = 6.f;      // vrt_hip_set_cull_prune(): a block-kernel ray may drop the smallest entries of its list while their sum stays below
@@ -123,9 +120,9 @@ struct vrt_hip_ctx {
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
     DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
-    int render_nw = 1;            // waves per block in the block kernel (VRT_HIP_RENDER_NW = 1 | 2): see render_kernel
     int render_waves_per_cu = 13; // persistent one-wave workgroups per CU: what LDS allows (VGPRs: three per SIMD run at a time; the
                                   // 13th starts when the first retires); VRT_HIP_RENDER_WAVES overrides
+    uint32_t render_grid_override = 0; // VRT_HIP_RENDER_GRID (tests): exactly this many block-kernel workgroups, e.g. ONE wave that drains all work queues
     uint32_t cells_x = 1, cells_y = 1, cstride = 1, n_cells = 0;
     int lists_for_shard = -1; // sharding mode the cell lists were built for
     bool prep_pending = false; // the per-origin table (gA) of gA_origin is still to be written: by the next list kernel, or by flush_prep()
@@ -146,7 +143,7 @@ struct vrt_hip_ctx {
     float table_room = 0.9f;      // share of the budget the kernel's ESTIMATE of its bound may fill when it coarsens the spacing (VRT_HIP_TABLE_ROOM)
     float table_adapt = 3.f;      // the table kernel may coarsen the requested spacing by up to this factor where its estimate of the
                                   // bound leaves room (VRT_HIP_TABLE_ADAPT; 1 = never)
-    int dense_idle_grid = 1; // workgroups of the dense launch when nothing is expected for it (VRT_HIP_DENSE_IDLE_GRID): one
+    static constexpr int dense_idle_grid = 1; // workgroups of the dense launch when nothing is expected for it: one
                              // 1024-thread workgroup finds a CU with 61 KB of LDS free sooner than eight do (-2 % with frames in flight)
     int dense_waves = 16; // waves per block in the dense kernel (tuning knob: VRT_HIP_DENSE_WAVES = 4 | 8 | 16)
     bool work_is_ref = false; // render straight from the ref lists (no tile-level cull possible)
@@ -442,7 +439,6 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
     g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.table_room = c->table_room; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
-    g.pair_lanes = c->pair_lanes;
     g.claim_early = c->claim_early;
     // prune_list sums sigma*mag*exp(-x) in units of the TILE level's eps (cull_x = ln(sigma*mag / eps_eff), rebuild_tables)
     g.prune_budget = (c->cull_eps > 0.f) ? c->cull_prune * (c->cull_ref_n > 0.f ? c->cull_ref_n : 4096.f / 3.f) * std::max(1.f, (float)c->n / 4096.f) / c->albedo_scale : 0.f;
@@ -506,7 +502,7 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
         a.cull_ref_n = c->cull_ref_n; a.floor_x = exp_floor_x(c->exp_kind);
         a.tile_w = geo.tile_w; a.tile_h = geo.tile_h; a.stride = geo.stride;
     }
-    if (refine && c->cache_cones) {
+    if (refine) {
         std::string key((const char *)&a.R, sizeof a.R);
         const uint32_t geo_key[6] = { geo.tile_w, geo.tile_h, geo.stride, geo.tiles_w, geo.tiles_h, c->plane_gen };
         key.append((const char *)geo_key, sizeof geo_key);
@@ -740,7 +736,8 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     c->last.rays = (uint64_t)o.n_local_tiles * t.tile_w * t.tile_h;
     // persistent grid: 12 one-wave workgroups per CU (three per SIMD at 145 VGPRs), never more than there are blocks
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u,
-                                                       (uint64_t)c->num_cus * std::max(1, c->render_waves_per_cu / c->render_nw));
+                                                       c->render_grid_override ? (uint64_t)c->render_grid_override
+                                                                               : (uint64_t)c->num_cus * std::max(1, c->render_waves_per_cu));
     if (out_mode == OUT_SPARSE && grid == 0) // a rank without cells launches no render kernel: nobody writes the header
         HIPCHK(c, hipMemsetAsync(d_image, 0, SPARSE_HDR_WORDS * sizeof(uint32_t), st));
     if (!c->lists_fresh) // a re-render from unchanged lists: only the dense kernel's work counters need a reset
@@ -788,7 +785,6 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
     cg.rq_next = c->c_rq.p + ((c->rq_gen + 1) & 1) * RQ_N * RQ_STRIDE;
     if (c->defer) {
         // a frame of a batch: the launches are made once for all frames by vrt_hip_frame_batch_device
-        if (c->render_nw != 1) return fail(c, VRT_HIP_ERR_INVALID, "frame batch: two waves per block are not batched");
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
         if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
         if (no_dense_work) dense_grid = 0;
@@ -804,7 +800,7 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         return VRT_HIP_OK;
     }
     if (tev) HIPCHK(c, hipEventRecord(tev[1], st));
-    launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->render_nw, c->exp_kind, c->erf_kind, st);
+    launch_render(tables(c), t, cg, ray_gen(c, origin), o, grid, c->exp_kind, c->erf_kind, st);
     if (tev) HIPCHK(c, hipEventRecord(tev[2], st));
     // dense queue: 16-wave workgroups pull blocks until the queue is empty (they exit at once if it is)
     if (expect_dense && !no_dense_work) launch_order_dense(cg, st);
@@ -924,6 +920,7 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
         const int v = atoi(e);
         if (v >= 1 && v <= 16) c->render_waves_per_cu = v;
     }
+    if (const char *e = getenv("VRT_HIP_RENDER_GRID")) c->render_grid_override = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("VRT_HIP_CULL_REF_N")) c->cull_ref_n = fmaxf(0.f, (float)atof(e));
     if (const char *e = getenv("VRT_HIP_CHUNKS")) c->use_chunks = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("VRT_HIP_CULL_PRUNE")) c->cull_prune = fmaxf(0.f, (float)atof(e));
@@ -931,19 +928,8 @@ int vrt_hip_create(int device, vrt_hip_ctx **out)
     if (const char *e = getenv("VRT_HIP_TABLE_ROOM")) { const float v = (float)atof(e); if (v > 0.f && v <= 10.f) c->table_room = v; }
     if (const char *e = getenv("VRT_HIP_TABLE_ADAPT")) { const float v = (float)atof(e); if (v >= 1.f && v <= 3.f) c->table_adapt = v; }
     if (const char *e = getenv("VRT_HIP_TABLE_BUDGET")) { const float v = (float)atof(e); if (v > 0.f) c->table_budget = v; }
-    if (const char *e = getenv("VRT_HIP_TILE_CONES")) c->cache_cones = atoi(e) != 0;
-    if (const char *e = getenv("VRT_HIP_LIGHT_CELLS")) c->light_cells = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("VRT_HIP_CLAIM_EARLY")) c->claim_early = std::max(0, atoi(e));
-    if (const char *e = getenv("VRT_HIP_PAIR_LANES")) c->pair_lanes = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("VRT_HIP_DENSE_SKIP")) c->skip_idle_dense = atoi(e) != 0;
-    if (const char *e = getenv("VRT_HIP_DENSE_IDLE_GRID")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 256) c->dense_idle_grid = v;
-    }
-    if (const char *e = getenv("VRT_HIP_RENDER_NW")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2) c->render_nw = v;
-    }
     if (const char *e = getenv("VRT_HIP_DENSE_WAVES")) {
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 17) c->dense_waves = v; // 17 = 16 waves without saturation skipping (A/B)
@@ -1626,9 +1612,8 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
     for (int i = 0; i < n; ++i) rows[i].do_order = ctxs[i]->deferred.order ? 1 : 0;
     // one-wave kernel: the persistent grid of ONE frame fills the GPU; n frames share it -- so a frame of a batch has 1/n of the waves and
     // that many more queue entries: the variant that claims them early is chosen against the per-frame grid
-    static const uint32_t oversub = [] { const char *e = getenv("VRT_HIP_BATCH_OVERSUB"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
     const uint32_t full_grid = c0->deferred.render_grid;
-    const uint32_t rgrid = full_grid ? std::min(full_grid, std::max(1u, (full_grid * oversub + (uint32_t)n - 1) / (uint32_t)n)) : 0u;
+    const uint32_t rgrid = full_grid ? std::min(full_grid, std::max(1u, (full_grid + (uint32_t)n - 1) / (uint32_t)n)) : 0u;
     bool claim = false;
     for (int i = 0; i < n; ++i) {
         const vrt_hip_ctx *c = ctxs[i];

@@ -19,7 +19,7 @@ constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate c
 #define VRT_PL 48
 #endif
 constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each; 96 since round 3 = the dense threshold: a block of
-                                  // this kernel never has more; the two kilobytes went to the pair-lane path's rows of per-ray values)
+                                  // this kernel never has more)
 #ifndef VRT_DCAP
 #define VRT_DCAP 1024
 #endif
@@ -83,7 +83,6 @@ struct CellGrid {
     float prune_budget;              // block kernel: a ray may drop the smallest entries of its list while their sum (units of the tile level's eps) stays below this (prune_list; 0 = off)
     int claim_early;                 // block kernel: a wave claims its next queue entry before it shades the current block when the queues hold at least
                                      // 1/claim_early of the grid size in entries (VRT_HIP_CLAIM_EARLY; 0: never -- after the block, as in rounds 1-2)
-    int pair_lanes;                  // block kernel: blocks with short per-ray lists are shaded with (ray, emitter) pairs as lanes (shade_pairs)
     // Launch feedback (host-mapped memory, nullable): [0] = dense cells of the frame, [1] = blocks of its active cells (written by the one-wave kernel),
     // [2] = items (blocks) the dense kernel found in its queues, [3] = sequence number of the frame that wrote [2]
     // The host reads it frames later to SIZE the dense launch: a frame that is expected to have nothing
@@ -164,7 +163,7 @@ void launch_build_static(uint32_t n, const float *mu_x, const float *mu_y, const
                          float cull_eps, float exp_floor_x, float4 *mu_sig, float4 *gB, float4 *gC, float4 *gD,
                          hipStream_t st);
 void launch_render(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r, const RenderTarget &o,
-                   uint32_t grid /* workgroups */, int nw /* waves per block: 1 or 2 */, int exp_kind, int erf_kind, hipStream_t st);
+                   uint32_t grid /* one-wave workgroups */, int exp_kind, int erf_kind, hipStream_t st);
 void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int dw /* waves per block: 4, 8 or 16 */, int exp_kind,
                          int erf_kind, hipStream_t st);

@@ -53,6 +53,9 @@ struct TableLds {
     };
     float st_r[2][TB_CH];                      // r_j of the staged absorbers
 };
+// 152 KB of the 160 KB of LDS a gfx950 CU has (one workgroup per CU): this translation unit is gfx950-only; another ARCH needs a smaller
+// TB_GMAX (or a build whose host keeps table_on() false)
+static_assert(sizeof(TableLds) + 512 <= 160 * 1024, "TableLds must fit the 160 KB of LDS of a gfx950 CU");
 
 // one pass over the survivors for the NT nodes [g0, g0 + NT) of this wave; tab[g] = sum_j A_j (E_j - Erf(x_gj)), summed per term
 // like the exact kernels (C - sum A_j Erf would round at the magnitude of sum |A_j|: 5e-5 of radiance for 1500 wide Gaussians,

@@ -239,6 +239,48 @@ class SparseFrameGatherer:
         self.regathered = 0
         self.bytes_moved = 0
         self.frames_moved = 0
+        # per-phase timers (off in a timed region: a pair of events per phase and batch).  With `timing` on, run() notes for every
+        # batch: "render" (unless the caller's render_batch notes it on its own stream), "gather" = from the moment the collective is
+        # enqueued until the frame stream may use its result (an UPPER bound of the collective: the frame stream also carries the
+        # older batches' assembly), "gather_nccl" = the collective's own duration where the backend reports it
+        # (TORCH_NCCL_ENABLE_TIMING=1), "assemble", and the host time spent inside run().  phase_ms() sums them.
+        self.timing = False
+        self._spans = []
+        self._g0 = [None] * NB
+        self.host_ms = 0.0
+        self.timed_frames = 0
+
+    def mark(self, stream=None):
+        """A time stamp for the phase timers: a CUDA event on `stream` (default: the current one), or the host clock."""
+        if not self.timing:
+            return None
+        if str(self.device) != "cpu":
+            import torch
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream) if stream is not None else ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
+    def note(self, kind, a, b):
+        if a is not None and b is not None:
+            self._spans.append((kind, a, b))
+
+    def phase_ms(self):
+        """{phase: total ms} of everything noted so far (waits for the events), then forgets it."""
+        out = {}
+        for kind, a, b in self._spans:
+            if isinstance(a, float):
+                ms = (b - a) * 1e3 if kind != "gather_nccl" else float(b)
+            else:
+                b.synchronize()
+                ms = a.elapsed_time(b)
+            out[kind] = out.get(kind, 0.0) + ms
+        out["host_in_run"] = self.host_ms
+        out["frames"] = self.timed_frames
+        out["batches_gathered_twice"] = self.regathered
+        self._spans, self.host_ms, self.timed_frames = [], 0.0, 0
+        return out
 
     def shard_frame(self, b, f):
         return self.shard[b][f * self.words:(f + 1) * self.words]
@@ -274,6 +316,7 @@ class SparseFrameGatherer:
     def start(self, b, nf):
         import torch
         frames = self.shard[b].view(self.F, self.words)[:nf]
+        self._g0[b] = self.mark()
         most = frames[:, 0].max().reshape(1).to(torch.int64)          # cells of the fullest shard of this batch, this rank
         if self.stage:
             most = most.cpu()
@@ -301,9 +344,17 @@ class SparseFrameGatherer:
         NB = self.NB
         pending, nfs, busy, order = [None] * NB, [0] * NB, [False] * NB, []
 
+        import time
+        t_run = time.perf_counter()
+
         def finish(b):
             if pending[b] is not None:
                 pending[b].wait()
+                if self.timing:
+                    try:                                              # the collective's own duration, where the backend keeps it
+                        self.note("gather_nccl", 0.0, float(pending[b]._get_duration()))
+                    except Exception:
+                        pass
             if self.most[b] is not None:                              # the deferred check of this batch's prefix
                 if self.most_ready[b] is not None:
                     self.most_ready[b].synchronize()
@@ -315,12 +366,15 @@ class SparseFrameGatherer:
                     again = self._gather(b, nfs[b], most)
                     if again is not None:
                         again.wait()
+            self.note("gather", self._g0[b], self.mark())
             if self.rank == 0:
+                a0 = self.mark()
                 if assemble_batch is not None:
                     assemble_batch(b, nfs[b])
                 else:
                     for f in range(nfs[b]):
                         assemble(b, f)
+                self.note("assemble", a0, self.mark())
             pending[b], busy[b] = None, False
 
         F = self.F
@@ -330,13 +384,18 @@ class SparseFrameGatherer:
                 order.remove(b)
                 finish(b)
             if render_batch is not None:
-                render_batch(b, nf)
+                render_batch(b, nf)                # (notes its own "render" span: it runs on a stream of its own)
             else:
+                r0 = self.mark()
                 for f in range(nf):
                     render(b, f)
+                self.note("render", r0, self.mark())
             nfs[b], pending[b], busy[b] = nf, self.start(b, nf), True
             order.append(b)
             while len(order) > NB - 1:            # oldest first: frames are assembled in the order they were rendered
                 finish(order.pop(0))
         while order:
             finish(order.pop(0))
+        if self.timing:
+            self.host_ms += (time.perf_counter() - t_run) * 1e3
+            self.timed_frames += nsteps

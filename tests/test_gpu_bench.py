@@ -54,3 +54,13 @@ def test_bench_line(tmp_path, steps, in_flight):
     ret = sw.pop("retained_frame_buffers")
     assert sorted(sw) == [str(k) for k in range(1, in_flight + 1)] and all(0 < t < 0.2 for t in sw.values())
     assert 0 < ret["ms_per_step"] < 0.2 and 0 < ret["serial_ms_per_frame"] < 0.2
+    # what the speed costs in accuracy (round-3 verdict): the same loop at exact settings, and the oracle's verdict on the timed frame
+    ex = d["exact_settings"]
+    assert ex["frames_in_flight"] == in_flight and 0 < ex["ms_per_step"] < 0.2 and 0 < ex["ms_per_frame"] < 0.2
+    assert abs(ex["value"] - 2048 * 2048 / (ex["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * ex["value"]
+    assert ex["ms_per_step"] > 0.9 * d["ms_per_step"]            # the exact settings are not the faster ones
+    par = d["parity"]
+    assert par["pixels"] >= 256 and par["tolerance"] == 1e-4 and par["oracle_peak_radiance"] > 5e-3
+    assert 0 < par["max_abs"] <= par["bound"] <= 5e-5, par
+    assert par["timed_vs_exact_settings_max_abs"] <= par["bound"]
+    assert d["collective"] is None                                # N = 1: no collective

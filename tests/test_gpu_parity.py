@@ -249,6 +249,30 @@ def test_device_erf_exp_against_reference_tables(pkg, oracle, renderer):
     assert np.abs(renderer.eval_exp(pkg.EXP_SPLINE, xe) - gold["spline_exp"]).max() <= 1e-7
 
 
+def test_device_erf_exp_against_the_reference_held_tables(pkg, oracle, renderer):
+    """vrt_hip_eval_erf / _exp against the tables the reference itself holds (thesis/plots/cmp_{erf,exp}_approx.tex = the output of
+    tests/accuracy.cpp:9-58; fixture tests/golden/thesis_plots.npz): every series on the reference's own float-accumulated grids."""
+    plots = np.load(os.path.join(GOLDEN, "thesis_plots.npz"))
+    # device erf: the A&S rational with a 1-ulp reciprocal instead of the scalar reference's divide; the others as in the source
+    for kind, series, bound in ((pkg.ERF_AS, "abramowitz_stegun", 3e-7), (pkg.ERF_SPLINE, "spline", 3e-7),
+                                (pkg.ERF_SPLINE_MIRROR, "spline_mirror", 3e-7), (pkg.ERF_TAYLOR, "taylor", 2e-6),
+                                (pkg.ERF_LIBM, "std_erf", 3e-7)):
+        x, y = plots[f"cmp_erf_approx/{series}/x"], plots[f"cmp_erf_approx/{series}/y"]
+        assert len(x) == 121
+        err = np.abs(renderer.eval_erf(kind, x) - y).max()
+        assert err <= bound, (series, err)
+    xe = plots["cmp_exp_approx/vcl/x"]
+    v, y = renderer.eval_exp(pkg.EXP_VCL, xe), plots["cmp_exp_approx/vcl/y"]
+    assert (np.abs(v - y) <= 2.5e-7 * np.abs(y)).all()                       # ~2 ulp: v_exp_f32-free restatement of exp_f
+    assert (v.view(np.uint32) == y.view(np.uint32)).mean() >= 0.5
+    fe, fy = renderer.eval_exp(pkg.EXP_FAST, xe), plots["cmp_exp_approx/fast/y"]
+    assert (np.abs(fe - fy) <= 1e-5 * np.abs(fy)).all()
+    se, sy = renderer.eval_exp(pkg.EXP_SPLINE, xe), plots["cmp_exp_approx/spline/y"]
+    assert np.abs(se - sy).max() <= 1e-7
+    le, ly = renderer.eval_exp(pkg.EXP_LIBM, xe), plots["cmp_exp_approx/std_exp/y"]
+    assert (np.abs(le - ly) <= 2.5e-7 * np.abs(ly)).all()
+
+
 def test_obj_scene_sparse(pkg, oracle, renderer):
     """-f monkey.obj at 512^2, rotated view: irregular per-ray Gaussian counts; oracle on sparse pixels."""
     w = h = 512
@@ -578,6 +602,21 @@ def test_work_queues_and_scheduling_do_not_change_the_image(pkg, oracle, rendere
             np.testing.assert_array_equal(rad, ref_rad)
     finally:
         r1.close()
+    # Round-3 advisor finding: the mask of queues a wave has seen run out was 32 bits wide for 64 queues.  One, two and three waves for
+    # the whole frame (VRT_HIP_RENDER_GRID): a wave works its way through all 64 queues, the lowest relative index first, so at the end
+    # of its launch only queues with relative index >= 32 still hold entries -- and with two or three waves they race for the last ones
+    # (the bits of queues 32..63 are set).  Every block must still be shaded exactly once.
+    for grid in ("1", "2", "3"):
+        monkeypatch.setenv("VRT_HIP_RENDER_GRID", grid)
+        r2 = pkg.Renderer(0)
+        try:
+            setup_scene(pkg, oracle, r2, g, w, h)
+            for _ in range(2):
+                img, rad = r2.render(origin)
+                np.testing.assert_array_equal(img, ref_img, err_msg=f"grid {grid}")
+                np.testing.assert_array_equal(rad, ref_rad, err_msg=f"grid {grid}")
+        finally:
+            r2.close()
 
 
 def test_cull_threshold_scales_with_the_scene_size(pkg, oracle, renderer):

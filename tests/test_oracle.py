@@ -1,8 +1,9 @@
 """CPU tests of the oracle (the checker must itself be pinned before it judges the HIP path).
 
-  - erf/exp restatements against golden tables generated from the REAL reference approx.cpp
-    (tests/golden/approx_ref.npz, made by tests/golden/gen_approx_golden.py) and, where
-    /root/reference is present, against that reference compiled in place (oracle/_ref);
+  - erf/exp restatements against the tables the reference ITSELF holds (thesis/plots/cmp_{erf,exp}_*.tex = the output of
+    tests/accuracy.cpp; tests/golden/thesis_plots.npz), against golden tables generated from the REAL reference approx.cpp
+    (tests/golden/approx_ref.npz, made by tests/golden/gen_approx_golden.py) and, where /root/reference is present,
+    against that reference compiled in place (oracle/_ref);
   - the reference test's own property (tests/transmittance.cpp:24-31): analytic transmittance ==
     numeric line integral of the density;
   - known answers for the scene producers, camera and tile binning;
@@ -38,6 +39,72 @@ def test_erf_exp_restatements_match_reference_tables(oracle, gold):
     assert np.abs(oracle.map_scalar("oracle_spline_exp", xe) - gold["spline_exp"]).max() <= 1.2e-7
     # A&S error bound quoted by the thesis (|err| <= 5e-4) against the true erf
     assert np.abs(oracle.map_scalar("oracle_as_erf", x) - gold["libm_erf"]).max() <= 5e-4
+
+
+@pytest.fixture(scope="module")
+def plots():
+    """What the REFERENCE ITSELF holds for erf / exp: the output of its accuracy experiment (tests/accuracy.cpp:9-58), kept in the
+    reference tree as thesis plot data (tests/golden/gen_thesis_plot_golden.py parses the numbers into thesis_plots.npz)."""
+    return np.load(os.path.join(GOLDEN, "thesis_plots.npz"))
+
+
+# restatement / device kernel name -> (plot series, stated bound on |restatement - the reference's printed value|)
+THESIS_ERF = {"oracle_as_erf": ("abramowitz_stegun", 1e-7), "oracle_spline_erf": ("spline", 1e-7),
+              "oracle_spline_erf_mirror": ("spline_mirror", 1e-7), "oracle_taylor_erf": ("taylor", 6e-7)}   # the reference binary is a -ffast-math build (FMA contraction): last-bit differences
+
+
+def test_restatements_match_the_reference_held_tables(oracle, plots):
+    """Row a12 pinned by reference-HELD vectors (round-3 verdict, missing item 1): every series of cmp_erf_approx.tex (121 points on
+    the float-accumulated grid -6, -5.9, ... , -5.7000003, ...) and cmp_exp_approx.tex (160 points) against the oracle restatements."""
+    for name, (series, bound) in THESIS_ERF.items():
+        x, y = plots[f"cmp_erf_approx/{series}/x"], plots[f"cmp_erf_approx/{series}/y"]
+        assert len(x) == 121 and x[0] == -6.0 and x[3] == np.float32(-5.7000003)
+        got = oracle.map_scalar(name, x)
+        assert np.abs(got - y).max() <= bound, (name, np.abs(got - y).max())
+    # most points agree to the bit (119 / 118 / 117 of 121 for A&S / spline / mirror)
+    x = plots["cmp_erf_approx/abramowitz_stegun/x"]
+    assert (oracle.map_scalar("oracle_as_erf", x).view(np.uint32) == plots["cmp_erf_approx/abramowitz_stegun/y"].view(np.uint32)).sum() >= 115
+    # exp: VCL bit for bit (every operation pinned); fast_exp within the product's rounding of the FMA build; spline to 1.2e-7 relative
+    xe = plots["cmp_exp_approx/vcl/x"]
+    assert len(xe) == 160 and xe[0] == -16.0
+    np.testing.assert_array_equal(oracle.map_scalar("oracle_vcl_exp", xe), plots["cmp_exp_approx/vcl/y"])
+    fe, fy = oracle.map_scalar("oracle_fast_exp", xe), plots["cmp_exp_approx/fast/y"]
+    assert (np.abs(fe - fy) <= 1e-5 * np.abs(fy)).all()
+    se, sy = oracle.map_scalar("oracle_spline_exp", xe), plots["cmp_exp_approx/spline/y"]
+    assert (np.abs(se - sy) <= 2e-7 * np.abs(sy) + 1e-12).all()
+    # the columns the approximations are judged against: std::erf / std::exp of the reference's libm, and SVML within its 4 ulp
+    import math
+    xs, ys = plots["cmp_erf_approx/std_erf/x"], plots["cmp_erf_approx/std_erf/y"]
+    assert np.abs(np.array([math.erf(float(v)) for v in xs]) - ys).max() <= 6e-8
+    assert np.abs(plots["cmp_erf_approx/svml/y"] - ys).max() <= 2.4e-7
+    xs, ys = plots["cmp_exp_approx/std_exp/x"], plots["cmp_exp_approx/std_exp/y"]
+    assert (np.abs(np.exp(xs.astype(np.float64)) - ys) <= 6e-8 * ys).all()
+    # the thesis's statement about A&S (|err| <= 5e-4) holds on the reference's own table
+    assert np.abs(plots["cmp_erf_approx/abramowitz_stegun/y"] - plots["cmp_erf_approx/std_erf/y"]).max() <= 5e-4
+
+
+def test_error_plots_follow_from_the_tables(oracle, plots):
+    """cmp_erf_err.tex is |std::erf - approximation| / |x| of the same run (julia/cmp_erf.jl:19-23; spline and mirror clamped to 0.1):
+    derived data, reproduced from the approx table's own columns and -- away from x = 0, where the division amplifies the last
+    bit -- from the oracle's restatements.  cmp_exp_err.tex comes from another run of the experiment (its x column is accumulated
+    differently: -0.09999881 against -0.0999975): only its statement is checked, VCL exp within 2 ulp of std::exp."""
+    std = plots["cmp_erf_approx/std_erf/y"].astype(np.float64)
+    for fn, series in (("oracle_as_erf", "abramowitz_stegun"), ("oracle_taylor_erf", "taylor")):
+        x, e = plots[f"cmp_erf_err/{series}/x"], plots[f"cmp_erf_err/{series}/y"]
+        np.testing.assert_array_equal(x, plots[f"cmp_erf_approx/{series}/x"])
+        far = np.abs(x) > 0.05
+        table = np.abs((std - plots[f"cmp_erf_approx/{series}/y"]) / x)
+        assert np.abs(table - e)[far].max() <= 1e-7, series
+        mine = np.abs((std - oracle.map_scalar(fn, x)) / x)
+        assert np.abs(mine - e)[far].max() <= 1e-5, series
+    for series in ("spline", "mirror"):   # clamped to 0.1 by the plotting script
+        assert plots[f"cmp_erf_err/{series}/y"].max() <= 0.1 + 1e-7
+    x, e = plots["cmp_exp_err/vcl/x"], plots["cmp_exp_err/vcl/y"]
+    assert (e * np.abs(x) <= 2.4e-7 * np.exp(x.astype(np.float64))).all()
+    # taylor_erf.tex is Julia's own evaluation (julia/approx_erf.jl), no output of the C++ path: only its erf column is checked
+    import math
+    xt, yt = plots["taylor_erf/erf/x"], plots["taylor_erf/erf/y"]
+    assert np.abs(np.array([math.erf(float(v)) for v in xt]) - yt).max() <= 1e-7
 
 
 def test_against_reference_built_in_place(oracle):
