@@ -135,8 +135,24 @@ def cpu_baseline(scene_mod, g, w, h, tiles_n, grid_dim, budget_note):
     t1 = time.perf_counter()
     _, terms1, _ = O.simd_render_tiled(256, 256, plane1, cam1.position[:], g1, tiles1, None, 1)
     dt1 = time.perf_counter() - t1
+    # how the port's speed relates to the real reference's on ONE host (the build container: profiles/rNN_cpu_port_vs_reference.md,
+    # made by tools/cpu_port_vs_reference.py against the survey's probe of the T-SIMD build; the reference cannot be rebuilt here)
+    import glob
+    import re
+    vs_ref, vs_ref_file = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_port_vs_reference.md")), reverse=True):
+        m = re.search(r"port_vs_reference_same_host:\s*([0-9.]+)\s*\.\.\s*([0-9.]+)", open(path).read())
+        if m:
+            vs_ref, vs_ref_file = [float(m.group(1)), float(m.group(2))], os.path.relpath(path, ROOT)
+            break
     return {
         "value": (w * h) / frame_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "port_vs_reference_same_host": vs_ref,
+        "note": ("own AVX-512 / AVX2 restatement of the reference's mode 8 doing its full per-term work, with the reference's call "
+                 "structure (from_gaussian_t and the A&S erf are real calls, four-component dot products, VCL exp's range check); "
+                 f"measured in the build container at {vs_ref[0]:.2f}-{vs_ref[1]:.2f} x the speed of the real T-SIMD build on the same "
+                 f"host and workloads ({vs_ref_file}): divide by that for the reference's own speed" if vs_ref else
+                 "own AVX-512 / AVX2 restatement of the reference's mode 8 doing its full per-term work"),
         "busy_threads": cpu_s / dt, "terms_per_s_per_busy_thread": terms / max(cpu_s, 1e-9),
         "sample": (f"all {ntiles} tiles x first {rows} pixel row(s) = {sample_rays} rays on {threads} threads "
                    f"({cpu_s / dt:.1f} busy on average), {terms:.3e} (ray,i,k,j) inner terms in {dt:.2f} s "
