@@ -314,9 +314,20 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
         if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
 
+        // The first 64 candidates' rows are requested BEFORE the ray set-up (round 4): queue entry -> list -> rows is the longest wait
+        // of a block, at the start of a launch every wave walks it at the same time, and the ~250 instructions of ray generation and
+        // cone fit behind the two round trips instead of in front of them.
+        const bool have0 = lane < n_list;
+        const uint32_t idx0 = have0 ? list[lane] : 0u;
+
         LaneRay ray = pixel_ray(R, pix);
         // the origin is wave-uniform (SGPRs): as a VGPR operand the 15 adds per emitter of the emission issue at full rate
         ray.ox = pin_vgpr(ray.ox); ray.oy = pin_vgpr(ray.oy); ray.oz = pin_vgpr(ray.oz);
+
+        float4 a0, bq0, ms0, alb0;
+        float q0 = 0.f;
+        a0 = bq0 = ms0 = alb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have0) { a0 = S.gA[idx0]; bq0 = S.gB[idx0]; ms0 = S.mu_sig[idx0]; alb0 = S.gC[idx0]; q0 = S.gD[idx0].y; }
 
         // ---- block cone: axis = mean of the four centre rays, angle = farthest lane ----
         float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
@@ -340,8 +351,11 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             float4 a, bq, ms, alb;
             float q;
             if (k < n_list) {
-                const uint32_t idx = list[k];
-                a = S.gA[idx]; bq = S.gB[idx]; ms = S.mu_sig[idx]; alb = S.gC[idx]; q = S.gD[idx].y;
+                if (base == 0) { a = a0; bq = bq0; ms = ms0; alb = alb0; q = q0; }
+                else {
+                    const uint32_t idx = list[k];
+                    a = S.gA[idx]; bq = S.gB[idx]; ms = S.mu_sig[idx]; alb = S.gC[idx]; q = S.gD[idx].y;
+                }
                 keep = cone_keeps(cone, a, make_float4(bq.x, bq.y, bq.z, slack_cull_x(bq.w, slack, T.floor_x)));
             }
             const unsigned long long mask = __ballot(keep);
@@ -439,9 +453,10 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
 }
 
 template <int EXP, int ERF, int EC, bool CLAIM = false>
-__global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+__global__ __launch_bounds__(64) VRT_RENDER_ATTR void render_kernel(RenderArgs) // read through kernel_args<>: vrt_kernels_common.hpp
 {
-    render_body<EXP, ERF, EC, CLAIM>(S, T, C, R, O);
+    const RenderArgs &a = kernel_args<RenderArgs>();
+    render_body<EXP, ERF, EC, CLAIM>(a.S, a.T, a.C, a.R, a.O);
 }
 // several frames per launch: blockIdx.y is the frame (FrameArgs)
 template <int EXP, int ERF, int EC, bool CLAIM = false>
@@ -457,8 +472,8 @@ static void launch_render_t(const SceneTables &s, const TileLists &t, const Cell
 {
     if (grid == 0) return;
     if (c.claim_early > 0 && EXP == VRT_EXP_VCL && ERF == VRT_ERF_AS) // frames with many more blocks than waves (the default pair only: compile time)
-        hipLaunchKernelGGL((render_kernel<VRT_EXP_VCL, VRT_ERF_AS, 4, true>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
-    else hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3(grid), dim3(64), 0, st, s, t, c, r, o);
+        hipLaunchKernelGGL((render_kernel<VRT_EXP_VCL, VRT_ERF_AS, 4, true>), dim3(grid), dim3(64), 0, st, RenderArgs{ s, t, c, r, o });
+    else hipLaunchKernelGGL((render_kernel<EXP, ERF, 4>), dim3(grid), dim3(64), 0, st, RenderArgs{ s, t, c, r, o });
 }
 
 template <int EXP, int ERF>

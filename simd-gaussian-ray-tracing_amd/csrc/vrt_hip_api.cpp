@@ -118,7 +118,7 @@ struct vrt_hip_ctx {
                                  // cull_prune * cull_ref_n * cull_eps (prune_list; 0 = off).  6: 3 * 6 * 1365 * 1e-9 = 2.46e-5 -- DESIGN.md section 4
     float cull_ref_n = 4096.f / 3.f; // TileLists::cull_ref_n; VRT_HIP_CULL_REF_N=0: one threshold at every level (round 1)
     // second level: 32x32-pixel cells of the local tiles + the active / dense queues of the render kernels
-    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_overflow2, c_counters, c_rq, c_slot;
+    DevBuf<uint32_t> c_count, c_indices, c_active, c_dense, c_dense_sorted, c_scratch, c_overflow, c_counters, c_rq, c_slot;
     uint32_t rq_gen = 0;      // render launches: selects the work-queue counter set (CellGrid::rq)
     int render_waves_per_cu = 13; // persistent one-wave workgroups per CU: what LDS allows (VGPRs: three per SIMD run at a time; the
                                   // 13th starts when the first retires); VRT_HIP_RENDER_WAVES overrides
@@ -438,7 +438,7 @@ CellGrid cell_grid(const vrt_hip_ctx *c)
     g.n_light = cnt + 1; g.light_threshold = c->lists_light; // as the lists in the buffers were built
     g.dense_next = cnt + 3;
     g.overflow = c->c_overflow.p; g.n_overflow = cnt + 4;
-    g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.table_room = c->table_room; g.overflow2 = c->c_overflow2.p; g.n_overflow2 = cnt + 5; // [6]: work counter of the exact kernel behind the table kernel, [7]: stays 0
+    g.table_hx = table_on(c) ? c->table_hx : 0.f; g.table_budget = c->table_budget; g.table_adapt = c->table_adapt; g.table_room = c->table_room;
     g.claim_early = c->claim_early;
     // prune_list sums sigma*mag*exp(-x) in units of the TILE level's eps (cull_x = ln(sigma*mag / eps_eff), rebuild_tables)
     g.prune_budget = (c->cull_eps > 0.f) ? c->cull_prune * (c->cull_ref_n > 0.f ? c->cull_ref_n : 4096.f / 3.f) * std::max(1.f, (float)c->n / 4096.f) / c->albedo_scale : 0.f;
@@ -479,7 +479,6 @@ int build_work_lists(vrt_hip_ctx *c, const float origin[3], hipStream_t st, bool
     HIPCHK(c, c->c_slot.reserve(c->n_cells));
     HIPCHK(c, c->c_scratch.reserve((size_t)c->num_cus * 4 * c->cstride)); // one slot per dense workgroup (<= 4 per CU)
     HIPCHK(c, c->c_overflow.reserve((size_t)c->n_cells * 16));
-    if (table_on(c)) HIPCHK(c, c->c_overflow2.reserve((size_t)c->n_cells * 16));
     HIPCHK(c, c->c_indices.reserve((size_t)c->n_cells * c->cstride));
     if (!c->c_counters.p) {
         HIPCHK(c, c->c_counters.reserve(16));
@@ -790,12 +789,6 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         if (no_dense_work) dense_grid = 0;
         FrameArgs &fa = *c->defer;
         fa.S = tables(c); fa.T = t; fa.C = cg; fa.R = ray_gen(c, origin); fa.O = o;
-        fa.C2 = cg;
-        if (table_on(c)) { // the exact kernel behind the table kernel works off the queue of declined blocks (as below)
-            uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
-            fa.C2.n_dense = cnt + 7; fa.C2.n_overflow = cnt + 5; fa.C2.overflow = c->c_overflow2.p; fa.C2.dense_next = cnt + 6;
-            fa.C2.feedback = nullptr;
-        }
         c->deferred.render = true; c->deferred.render_grid = grid; c->deferred.order = expect_dense && !no_dense_work; c->deferred.dense_grid = dense_grid;
         return VRT_HIP_OK;
     }
@@ -808,14 +801,10 @@ int render_common(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32_
         uint32_t dense_grid = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cells * 16u, (uint64_t)c->num_cus * (16 / std::min(c->dense_waves, 16)));
         if (!expect_dense) dense_grid = std::min(dense_grid, (uint32_t)(camera_moved ? std::max(c->dense_idle_grid, c->num_cus / 4) : c->dense_idle_grid));
         if (table_on(c)) {
-            // table mode (the default): the table kernel takes the whole dense queue and hands what it declines to a second
-            // queue, which the exact kernel then works off (n_dense reads the always-zero word of the counter set)
+            // table mode (the default): the table kernel takes the whole dense queue; a block it declines it shades exactly itself
+            // (dense_shade_block in its own LDS): ONE dense-path launch per frame (rounds 1-3: an exact launch behind it, idle in
+            // every frame of a moving camera)
             launch_render_table(tables(c), t, cg, ray_gen(c, origin), o, std::min<uint32_t>(dense_grid, (uint32_t)c->num_cus), c->exp_kind, c->erf_kind, st);
-            CellGrid cq = cg;
-            uint32_t *cnt = c->c_counters.p + 8 * (c->list_gen & 1);
-            cq.n_dense = cnt + 7; cq.n_overflow = cnt + 5; cq.overflow = c->c_overflow2.p; cq.dense_next = cnt + 6;
-            cq.feedback = nullptr;
-            launch_render_dense(tables(c), t, cq, ray_gen(c, origin), o, dense_grid, c->dense_waves, c->exp_kind, c->erf_kind, st);
         } else {
             launch_render_dense(tables(c), t, cg, ray_gen(c, origin), o, dense_grid, c->dense_waves, c->exp_kind, c->erf_kind, st);
         }
@@ -953,7 +942,7 @@ void vrt_hip_destroy(vrt_hip_ctx *c)
     c->mu_sig.release(); c->gA.release(); c->gB.release(); c->gC.release(); c->gD.release(); c->iota.release();
     c->ref_start.release(); c->ref_count.release(); c->ref_indices.release();
     c->w_start.release(); c->w_count.release(); c->w_indices.release(); c->xc.release(); c->yc.release();
-    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_overflow2.release(); c->c_counters.release(); c->c_rq.release(); c->c_slot.release();
+    c->c_count.release(); c->c_indices.release(); c->c_active.release(); c->c_dense.release(); c->c_dense_sorted.release(); c->c_scratch.release(); c->c_overflow.release(); c->c_counters.release(); c->c_rq.release(); c->c_slot.release();
     c->xs.release(); c->ys.release(); c->zs.release(); c->tile_map.release(); c->slot_tiles.release();
     c->d_image.release(); c->own_stamp.release(); c->d_rad.release(); c->d_stats.release(); c->d_timeline.release(); c->d_timeline_lists.release();
     if (c->h_fb) (void)hipHostFree((void *)c->h_fb);
@@ -1632,7 +1621,7 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
     for (int i = 0; i < n; ++i) dgrid = std::max(dgrid, ctxs[i]->deferred.dense_grid);
     launch_order_dense_batch(d_rows, rows, (uint32_t)n, st);
     if (table_on(c0))
-        launch_render_table_batch(d_rows, (uint32_t)n, std::min<uint32_t>(dgrid, (uint32_t)c0->num_cus), dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
+        launch_render_table_batch(d_rows, (uint32_t)n, std::min<uint32_t>(dgrid, (uint32_t)c0->num_cus), c0->exp_kind, c0->erf_kind, st);
     else
         launch_render_dense_batch(d_rows, (uint32_t)n, dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
     HIPCHK(c0, hipGetLastError());

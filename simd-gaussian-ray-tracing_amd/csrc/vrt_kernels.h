@@ -74,6 +74,7 @@ struct CellGrid {
     // the BACK of `active` (n_light of them: active[n_cells - 1 - k]) and shaded last: a frame rarely has a multiple of the
     // GPU's wave slots in blocks, and the blocks that run as a fourth wave on their SIMD should be the cheap ones.
     // Raster frames only: a sparse shard needs its cells in one contiguous run of slots (light_threshold = 0 there).
+    // (Round 4 tried to queue only the BLOCKS of light cells that some candidate reaches: tools/experiments/light_block_masks.patch.)
     uint32_t *n_light;
     uint32_t light_threshold;
     uint32_t *dense_next;            // work counter of the dense kernel (zeroed with the others)
@@ -95,14 +96,12 @@ struct CellGrid {
     // are pulled from RQ_N counters RQ_STRIDE words apart (item G + q + RQ_N*m is the m-th of queue q).  `rq` is this
     // launch's set (zero on entry), `rq_next` the other set, which this launch clears for the next one.
     uint32_t *rq, *rq_next;
-    // table mode (render_table_kernel): requested node spacing in units of 1/r (0 = off), the largest change of a ray's
-    // radiance the table may cause (worst-case bound, checked per ray), and the queue of the blocks it declines, which
-    // the exact dense kernel works off afterwards
+    // table mode (render_table_kernel): requested node spacing in units of 1/r (0 = off) and the largest change of a ray's
+    // radiance the table may cause (worst-case bound, checked per ray; a block that fails it is shaded exactly by the same workgroup)
     float table_hx, table_budget;
     float table_room;                // ... and the share of the budget its estimate may fill when it does (the estimate is not the bound)
     float table_adapt;               // the table kernel may choose a spacing up to this many times the requested one where its estimate
                                      // of the error bound leaves room (1 = always as requested)
-    uint32_t *overflow2, *n_overflow2;
 };
 #ifndef VRT_RQ_N
 #define VRT_RQ_N 64
@@ -226,7 +225,6 @@ void launch_build_chunks(uint32_t n, const float4 *mu_sig, const float4 *gB, flo
 struct FrameArgs {
     BinArgs bin; FuseArgs fuse;                                   // list kernel
     SceneTables S; TileLists T; CellGrid C; RayGen R; RenderTarget O;   // one-wave kernel and dense kernel
-    CellGrid C2;                                                  // table mode: the exact kernel's view of the queue of declined blocks
     // the frame's small set-up kernels, batched too (a launch per frame and member costs more than the work: 512 launches of
     // 14-20 us in a 128-frame orbit on four members, profiles/r03_group.md)
     int do_prep;  float4 *prep_gA; float prep_origin[3];          // prep_frame_kernel: oc = mu - origin, |oc|^2
@@ -240,8 +238,7 @@ void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint
 // the per-frame set-up kernels of a batch, one launch each: prep_frame (grid.y = frame), tile_cones, order_dense
 void launch_frame_setup_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st);
 void launch_order_dense_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st);
-void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, int exp_kind, int erf_kind,
-                               hipStream_t st);
+void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,
                      uint32_t world, uint64_t rank_stride, const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
 void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);

@@ -1,45 +1,19 @@
 // vrt_kernels.hip -- exact dense kernel, list kernels (tile binning rt.cpp:29-69 + cell lists), scene tables, frame assembly
 // (multi-GPU) and the point queries.  The block kernel and the table kernel live in vrt_block_kernel.hip / vrt_table_kernel.hip;
 // what all three share is in vrt_kernels_common.hpp.
-#include "vrt_kernels_common.hpp"
+#include "vrt_dense_block.hpp"
 
 namespace vrtk {
 
-// ---------------------------------------------------------------------------------------------
-// Dense blocks (hundreds of candidates per 8x8 block: sigma of many pixels, rays of a block see the
-// same Gaussians).  One 16-wave workgroup per block: the block's candidates are culled cooperatively
-// into LDS once, the EMITTERS are dealt to the 16 waves (wave w takes chunks w, w+16, ...), every
-// wave streams all absorbers for its emitters out of LDS (wave-uniform broadcast reads), and the 16
-// partial radiances are summed in wave order -- deterministic, no float atomics.  Blocks are pulled
-// from a queue with one atomic per block (a block is >= 1e5 instructions; the counter is cold).
-// ---------------------------------------------------------------------------------------------
+// The exact dense kernel: persistent DW-wave workgroups pull blocks (the cells of the dense queue, then what the block kernel handed
+// over) with one atomic per block and shade them with dense_shade_block (vrt_dense_block.hpp).
 template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
 __device__ __forceinline__ void render_dense_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R,
                                                   const RenderTarget &O)
 {
-    constexpr int DCAP = vrtk::DCAP;
-    // One block of LDS carved by hand: the two rows the absorber loop reads sit in the first 64 KB, where a DS
-    // instruction's 16-bit offset field reaches them (arrays placed beyond cost a VALU address add per read: +4 %).
-    struct Lds {
-        float4 A[DCAP], B[DCAP];          // sorted by depth
-        float4 L[DW][64];
-        uint32_t idx0[DCAP], idx[DCAP];   // "0": in list order; idx: sorted
-        float key[DCAP];
-    };
-    __shared__ Lds lds;
-    float4(&s_A)[DCAP] = lds.A;
-    float4(&s_B)[DCAP] = lds.B;
-    float4(&s_L)[DW][64] = lds.L;
-    uint32_t(&s_idx0)[DCAP] = lds.idx0;
-    uint32_t(&s_idx)[DCAP] = lds.idx;
-    float(&s_key)[DCAP] = lds.key;
-    __shared__ uint32_t s_wave_cnt[DW];
+    __shared__ DenseLds<DW> lds;
     __shared__ uint32_t s_item;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t npix = (uint64_t)R.width * R.height;
-    constexpr float SAT = erf_saturation<ERF>();
-    constexpr float SAT_M = SAT + 1e-3f; // the range bounds are re-associated forms of the arguments: keep a margin
-    const ErfEval<ERF> erf;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t n_dense16 = *C.n_dense * 16u, n_items = n_dense16 + *C.n_overflow;
     if (C.feedback && blockIdx.x == 0 && tid == 0) { // launch feedback: how much this frame had for this kernel
         __hip_atomic_store(&C.feedback[2], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -48,9 +22,7 @@ __device__ __forceinline__ void render_dense_body(const SceneTables &S, const Ti
     const uint32_t *dense_queue = C.dense_is_sorted ? C.dense_sorted : C.dense;
     uint32_t *scratch = C.scratch + (size_t)blockIdx.x * C.cstride;
     const unsigned long long t_start = O.stats ? wall_clock64() : 0ull;
-    // what the saturation tests decide, per (emitter chunk, absorber) visit of this wave (wave-uniform: scalar adds
-    // beside the vector work; written out only when statistics are on)
-    uint32_t n_visit_full = 0, n_visit_zero = 0, n_visit_common = 0;
+    DenseVisits visits;
 
     for (;;) {
         __syncthreads(); // everyone is done with the previous item's LDS
@@ -59,8 +31,8 @@ __device__ __forceinline__ void render_dense_body(const SceneTables &S, const Ti
         const uint32_t item = s_item;
         if (item >= n_items) {
             if (O.stats && lane == 0) {
-                atomicAdd(&O.stats[13], (unsigned long long)n_visit_full); atomicAdd(&O.stats[14], (unsigned long long)n_visit_zero);
-                atomicAdd(&O.stats[15], (unsigned long long)n_visit_common);
+                atomicAdd(&O.stats[13], (unsigned long long)visits.full); atomicAdd(&O.stats[14], (unsigned long long)visits.zero);
+                atomicAdd(&O.stats[15], (unsigned long long)visits.common);
             }
             if (O.stats && tid == 0) { // workgroup timeline: how long the queue kept this workgroup busy
                 const unsigned long long t_end = wall_clock64();
@@ -72,210 +44,20 @@ __device__ __forceinline__ void render_dense_body(const SceneTables &S, const Ti
         uint32_t cell, bi;
         if (item < n_dense16) { cell = dense_queue[item >> 4]; bi = item & 15u; }
         else { const uint32_t packed = C.overflow[item - n_dense16]; cell = packed >> 4; bi = packed & 15u; }
-        const BlockPos p = block_of(T, C, O, cell, bi, lane);
-        if (!p.inside) continue;
-        const uint32_t tx = p.t % T.tiles_w, ty = p.t / T.tiles_w;
-        bool valid = p.pxt < T.tile_w && p.pyt < T.tile_h;
-        const uint32_t pxc = min(p.pxt, T.tile_w - 1), pyc = min(p.pyt, T.tile_h - 1);
-        uint64_t pix = (uint64_t)(tx * T.tile_w + pxc) + (uint64_t)T.stride * (ty * T.tile_h + pyc);
-        if (pix >= npix) { valid = false; pix = npix - 1; }
-        const uint32_t n_active_cells = *C.n_active;
-        const uint64_t out = out_index(T, C, O, cell, bi, lane, p, pix, n_active_cells);
-        if (O.sparse && item < n_dense16 && bi == 0 && tid == 0) // a dense cell's key (the active cells' are filed by the list kernel)
-            O.keys[n_active_cells + (C.slot[cell] & 0x7FFFFFFFu)] = p.t * (C.cells_x * C.cells_y) + cell % (C.cells_x * C.cells_y);
-
-        uint32_t n_list = C.count[cell];
-        const uint32_t *list = C.indices + (size_t)cell * C.cstride;
-        if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
-
-        const LaneRay ray = pixel_ray(R, pix); // every wave holds the same 64 rays
-        float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
-        float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
-        float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
-        {
-            const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy + cz * cz);
-            cx *= inv; cy *= inv; cz *= inv;
-        }
-        float co, si;
-        cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
-        const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
-
-        // ---- cooperative block cull, order preserving across the 16 waves ----
-        uint32_t cnt = 0;
-        for (uint32_t base = 0; base < n_list; base += DW * 64) {
-            const uint32_t k = base + tid;
-            bool keep = false;
-            uint32_t idx = 0;
-            float4 a, bq;
-            if (k < n_list) {
-                idx = list[k];
-                a = S.gA[idx]; bq = S.gB[idx];
-                bq.w = slack_cull_x(bq.w, level_slack(T.cull_ref_n, n_list), T.floor_x);
-                keep = cone_keeps(cone, a, bq);
-            }
-            const unsigned long long mask = __ballot(keep);
-            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
-            __syncthreads();
-            uint32_t before = 0, chunk = 0;
-#pragma unroll
-            for (uint32_t wv = 0; wv < DW; ++wv) {
-                const uint32_t c = s_wave_cnt[wv];
-                before += (wv < wave) ? c : 0;
-                chunk += c;
-            }
-            const uint32_t pos = cnt + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            if (keep && pos < DCAP) {
-                s_idx0[pos] = idx;
-                s_key[pos] = a.x * cone.cx + a.y * cone.cy + a.z * cone.cz; // depth along the block's axis
-            }
-            // the survivors also go to this workgroup's slot of global scratch: should they outgrow LDS, the fallback
-            // below streams THEM (cnt^2 pairs) and not the whole cell list (n_list^2)
-            if (keep && pos < C.cstride) scratch[pos] = idx;
-            cnt += chunk;
-            __syncthreads();
-        }
-        // ---- sort the candidates by depth (rank sort: every thread ranks one candidate against all keys) so
-        //      that the emitters of a chunk are neighbours in depth and whole absorbers saturate for them ----
-        if (cnt <= DCAP) {
-            for (uint32_t i = tid; i < cnt; i += DW * 64) {
-                const float ki = s_key[i];
-                uint32_t r = 0;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const float kk = s_key[k];
-                    r += (kk < ki || (kk == ki && k < i)) ? 1u : 0u;
-                }
-                const uint32_t idx = s_idx0[i];
-                s_idx[r] = idx; s_A[r] = S.gA[idx]; s_B[r] = S.gB[idx]; // rows come back from L2 (read a moment ago)
-            }
-        }
-        __syncthreads();
-        if (O.stats && tid == 0) {
-            atomicAdd(&O.stats[0], (unsigned long long)(cnt <= C.cstride ? cnt : n_list));
-            atomicAdd(&O.stats[1], (unsigned long long)n_list);
-            if (cnt > DCAP) atomicAdd(&O.stats[2], 1ull);
-            atomicAdd(&O.stats[6], 1ull);
-        }
-
-        float Lr = 0.f, Lg = 0.f, Lb = 0.f, La = 0.f;
-        if (cnt > DCAP) {
-            // does not fit LDS: every wave streams the block's survivors (written above by this workgroup: visible to
-            // all its waves after the barrier + fence) for its share of the emitters
-            __threadfence_block();
-            if (cnt <= C.cstride) shade_list<EXP, ERF, 4, true>(S, scratch, cnt, ray, Lr, Lg, Lb, La, wave * 4, DW * 4);
-            else shade_list<EXP, ERF, 4, true>(S, list, n_list, ray, Lr, Lg, Lb, La, wave * 4, DW * 4);
-        } else {
-            for (uint32_t i0 = wave * EC; i0 < cnt; i0 += DW * EC) {
-                float e_mubar[EC], e_sigma[EC];
-                uint32_t e_idx[EC];
-#pragma unroll
-                for (int e = 0; e < EC; ++e) {
-                    const uint32_t ii = (i0 + e < cnt) ? (i0 + e) : i0;
-                    e_idx[e] = __builtin_amdgcn_readfirstlane(s_idx[ii]);
-                    const float4 a = s_A[ii];
-                    e_mubar[e] = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
-                    e_sigma[e] = uload(S.gD, e_idx[e]).x;
-                }
-                float acc[EC][5];
-#pragma unroll
-                for (int e = 0; e < EC; ++e)
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) acc[e][k] = 0.f;
-
-                // Saturation: Erf(x) is EXACTLY +-1 in fp32 for |x| >= SAT.  An absorber j in front of the camera
-                // (m_j >= SAT => E_j = -1) whose Erf argument is <= -SAT at every sample of every emitter of the chunk
-                // on every ray of the block adds exactly A_j*(-1 - -1) = 0: skipped before even forming A_j.  One whose
-                // arguments are all >= SAT adds exactly -2 A_j to all 5*EC sums: one fma into `common`.
-                float common = 0.f;
-                float s_max = -INFINITY, s_min = INFINITY; // this ray's sample range over the chunk's emitters
-#pragma unroll
-                for (int e = 0; e < EC; ++e) {
-                    s_max = fmaxf(s_max, e_mubar[e]);
-                    s_min = fminf(s_min, __builtin_fmaf(-4.f, e_sigma[e], e_mubar[e]));
-                }
-                float4 a = s_A[0], b = s_B[0];
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    const float4 ca = a, cb = b;
-                    if (j + 1 < cnt) { a = s_A[j + 1]; b = s_B[j + 1]; }
-                    const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
-                    const float m = mubar * cb.x;
-                    // argument range over the chunk's samples on this ray: [(s_min - mubar_j) r_j, (s_max - mubar_j) r_j]
-                    const float hi = __builtin_fmaf(s_max, cb.x, -m), lo = __builtin_fmaf(s_min, cb.x, -m);
-                    const bool front = m >= SAT;
-                    if (SKIP && __all(front && hi <= -SAT_M)) { ++n_visit_zero; continue; }
-                    const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
-                    const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
-                    if (SKIP && __all(front && lo >= SAT_M)) { common = __builtin_fmaf(A, -2.f, common); ++n_visit_common; continue; }
-                    ++n_visit_full;
-                    const float E = erf(-m);
-#pragma unroll
-                    for (int e = 0; e < EC; ++e) {
-                        const float base = __builtin_fmaf(e_mubar[e], cb.x, -m);
-                        const float step = e_sigma[e] * cb.x;
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) {
-                            const float x = __builtin_fmaf((float)(k - 4), step, base);
-                            acc[e][k] = __builtin_fmaf(A, E - erf(x), acc[e][k]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < EC; ++e) {
-                    if (i0 + e < cnt) {
-                        const float4 ms = uload(S.mu_sig, e_idx[e]);
-                        const float inv2s2 = uload(S.gB, e_idx[e]).y;
-                        const float q = uload(S.gD, e_idx[e]).y;
-                        float inner = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) {
-                            const float sk = madd_ref((float)(k - 4), ms.w, e_mubar[e]);
-                            const float px = sub_ref(madd_ref(ray.nx, sk, ray.ox), ms.x);
-                            const float py = sub_ref(madd_ref(ray.ny, sk, ray.oy), ms.y);
-                            const float pz = sub_ref(madd_ref(ray.nz, sk, ray.oz), ms.z);
-                            const float dd = dot3_ref(px, py, pz, px, py, pz);
-                            inner += emission_term<EXP>(q, dd * inv2s2, acc[e][k] + common);
-                        }
-                        const float4 alb = uload(S.gC, e_idx[e]);
-                        Lr = __builtin_fmaf(alb.x, inner, Lr);
-                        Lg = __builtin_fmaf(alb.y, inner, Lg);
-                        Lb = __builtin_fmaf(alb.z, inner, Lb);
-                        La = __builtin_fmaf(alb.w, inner, La);
-                    }
-                }
-            }
-        }
-        // ---- sum the waves' partial radiances in wave order ----
-        s_L[wave][lane] = make_float4(Lr, Lg, Lb, La);
-        __syncthreads();
-        if (wave == 0 && valid) {
-            float4 sum = s_L[0][lane];
-#pragma unroll
-            for (int w = 1; w < DW; ++w) {
-                const float4 v = s_L[w][lane];
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-            }
-            if (O.image) O.image[out] = pack_pixel(sum.x, sum.y, sum.z, sum.w, O.pack_flags);
-            if (O.radiance) O.radiance[out] = sum;
-        }
+        dense_shade_block<EXP, ERF, EC, DW, SKIP>(S, T, C, R, O, lds, scratch, cell, bi, item < n_dense16, visits);
     }
 }
 template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
-__global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R,
-                                                                RenderTarget O)
+__global__ __launch_bounds__(DW * 64, 4) void render_dense_kernel(RenderArgs) // read through kernel_args<>: vrt_kernels_common.hpp
 {
-    render_dense_body<EXP, ERF, EC, DW, SKIP>(S, T, C, R, O);
+    const RenderArgs &a = kernel_args<RenderArgs>();
+    render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C, a.R, a.O);
 }
 template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
 __global__ __launch_bounds__(DW * 64, 4) void render_dense_batch_kernel(const FrameArgs *__restrict__ frames)
 {
     const FrameArgs &a = frames[blockIdx.y];
     render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C, a.R, a.O);
-}
-
-template <int EXP, int ERF, int EC, int DW, bool SKIP = true>
-__global__ __launch_bounds__(DW * 64, 4) void render_dense_batch2_kernel(const FrameArgs *__restrict__ frames)
-{
-    const FrameArgs &a = frames[blockIdx.y];
-    render_dense_body<EXP, ERF, EC, DW, SKIP>(a.S, a.T, a.C2, a.R, a.O);
 }
 
 // Queue order of the dense kernel: cells by descending candidate count (a block costs ~ count^2), so that the
@@ -330,10 +112,10 @@ static void launch_render_dense_t(const SceneTables &s, const TileLists &t, cons
                                   const RenderTarget &o, uint32_t grid, int dw, hipStream_t st)
 {
     if (grid == 0) return;
-    if (dw == 17) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16, false>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
-    else if (dw == 16) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
-    else if (dw == 8) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 8>), dim3(grid), dim3(512), 0, st, s, t, c, r, o);
-    else hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 4>), dim3(grid), dim3(256), 0, st, s, t, c, r, o);
+    if (dw == 17) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16, false>), dim3(grid), dim3(1024), 0, st, RenderArgs{ s, t, c, r, o });
+    else if (dw == 16) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 16>), dim3(grid), dim3(1024), 0, st, RenderArgs{ s, t, c, r, o });
+    else if (dw == 8) hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 8>), dim3(grid), dim3(512), 0, st, RenderArgs{ s, t, c, r, o });
+    else hipLaunchKernelGGL((render_dense_kernel<EXP, ERF, 6, 4>), dim3(grid), dim3(256), 0, st, RenderArgs{ s, t, c, r, o });
 }
 void launch_render_dense(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int dw, int exp_kind, int erf_kind, hipStream_t st)
@@ -354,25 +136,6 @@ void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint
                                hipStream_t st)
 {
     VRT_DISPATCH_EXP_ERF(launch_render_dense_batch_t, d_frames, nframes, grid, dw, st);
-}
-
-void launch_render_table_only_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st); // table TU
-template <int EXP, int ERF>
-static void launch_render_table_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid2, int dw, hipStream_t st)
-{
-    if (!nframes || !grid2) return;
-    const dim3 g(grid2, nframes);
-    if (dw == 17) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 16, false>), g, dim3(1024), 0, st, d_frames);
-    else if (dw == 16) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 16>), g, dim3(1024), 0, st, d_frames);
-    else if (dw == 8) hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 8>), g, dim3(512), 0, st, d_frames);
-    else hipLaunchKernelGGL((render_dense_batch2_kernel<EXP, ERF, 6, 4>), g, dim3(256), 0, st, d_frames);
-}
-// table kernel over the frames' dense queues, then the exact kernel over what it declined (FrameArgs::C2)
-void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint32_t grid2, int dw, int exp_kind, int erf_kind,
-                               hipStream_t st)
-{
-    launch_render_table_only_batch(d_frames, nframes, grid, exp_kind, erf_kind, st);
-    VRT_DISPATCH_EXP_ERF(launch_render_table_batch_t, d_frames, nframes, grid2, dw, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -856,10 +619,12 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
     if (tl) tl[5] = wall_clock64();
     write_prep();
 }
+struct ListArgs { BinArgs P; FuseArgs F; };
 template <bool FROM_LIST, bool CHUNKS = false>
-__global__ __launch_bounds__(1024) void build_tile_lists_kernel(BinArgs P, FuseArgs F)
+__global__ __launch_bounds__(1024) void build_tile_lists_kernel(ListArgs) // read through kernel_args<>: vrt_kernels_common.hpp
 {
-    build_tile_lists_body<FROM_LIST, CHUNKS>(P, F);
+    const ListArgs &a = kernel_args<ListArgs>();
+    build_tile_lists_body<FROM_LIST, CHUNKS>(a.P, a.F);
 }
 template <bool FROM_LIST, bool CHUNKS = false>
 __global__ __launch_bounds__(1024) void build_tile_lists_batch_kernel(const FrameArgs *__restrict__ frames)
@@ -871,9 +636,9 @@ __global__ __launch_bounds__(1024) void build_tile_lists_batch_kernel(const Fram
 void launch_build_tile_lists(const BinArgs &a, const FuseArgs &f, bool from_list, uint32_t ntiles, hipStream_t st)
 {
     if (!ntiles) return;
-    if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, a, f);
-    else if (a.chunks && a.refine) hipLaunchKernelGGL((build_tile_lists_kernel<false, true>), dim3(ntiles), dim3(1024), 0, st, a, f);
-    else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, a, f);
+    if (from_list) hipLaunchKernelGGL(build_tile_lists_kernel<true>, dim3(ntiles), dim3(1024), 0, st, ListArgs{ a, f });
+    else if (a.chunks && a.refine) hipLaunchKernelGGL((build_tile_lists_kernel<false, true>), dim3(ntiles), dim3(1024), 0, st, ListArgs{ a, f });
+    else hipLaunchKernelGGL(build_tile_lists_kernel<false>, dim3(ntiles), dim3(1024), 0, st, ListArgs{ a, f });
 }
 void launch_build_tile_lists_batch(const FrameArgs *d_frames, uint32_t nframes, bool from_list, bool chunks, uint32_t ntiles, hipStream_t st)
 {

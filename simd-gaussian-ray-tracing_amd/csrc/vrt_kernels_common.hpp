@@ -344,6 +344,19 @@ __device__ __forceinline__ bool cone_keeps(const Cone &k, float4 a /*oc,|oc|^2*/
 __device__ __forceinline__ float level_slack(float cull_ref_n, uint32_t n) { return cull_ref_n > 0.f ? __logf(cull_ref_n / (float)max(n, 1u)) : 0.f; }
 __device__ __forceinline__ float slack_cull_x(float cull_x, float slack, float floor_x) { return cull_x < floor_x ? cull_x - slack : cull_x; }
 
+// Kernel arguments through the kernarg segment pointer (round 4).  The render kernels take five argument structures (~140 dwords), the
+// list kernel two (~150).  As ordinary by-value parameters the compiler loads all of them into SGPRs at entry, keeps them live through
+// the kernel's loops and spills what does not fit to VGPR lanes -- the block kernel had 121 spilled SGPRs and ~370 v_readlane_b32 in its
+// per-block code, each a VALU issue slot.  Read through the segment pointer they are scalar loads at the place of use (the scalar cache
+// holds the few hundred bytes): 9 spilled SGPRs, 16 v_readlane_b32.  The frame-batch variants, whose arguments sit behind a pointer
+// anyway, never spilled.  The by-value parameter stays in the signature: it is what puts the bytes into the segment.
+struct RenderArgs { SceneTables S; TileLists T; CellGrid C; RayGen R; RenderTarget O; };
+template <typename Args>
+__device__ __forceinline__ const Args &kernel_args()
+{
+    return *(const Args *)__builtin_amdgcn_kernarg_segment_ptr(); // (a C-style cast: it leaves the constant address space)
+}
+
 // ---------------------------------------------------------------------------------------------
 // Work items of the shading kernels: an 8x8 pixel block (64 rays, lane = ray) of a 32x32 pixel cell
 // ---------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 // vrt_table_kernel.hip -- the table kernel: dense blocks through a per-ray table of the transmittance exponent.  A translation unit
 // of its own (the three kernel units compile side by side); the default scheduler (csrc/Makefile has the measurement).
 // gfx950 only: TableLds takes ~152 KB of the CU's 160 KB of LDS (static_assert below).
-#include "vrt_kernels_common.hpp"
+#include "vrt_dense_block.hpp"
 
 namespace vrtk {
 
@@ -22,8 +22,8 @@ namespace vrtk {
 // The kernel accumulates exactly this sum per ray (K from a per-ray pass over the A_j, kept as one byte per node) and
 // keeps a block only if every ray stays below the budget (CellGrid::table_budget, default 2.5e-5: with the cull thresholds'
 // 2.5e-5 the frame's worst case is 5e-5, half the 1e-4 tolerance).  A block that fails is tried once more at 0.6 of the
-// spacing and then handed to the exact kernel (second queue), as are blocks with more than 2048 survivors or a sample range
-// of more than 8 x 376 nodes.  The bound is a worst case (every kink at its worst phase,
+// spacing and then shaded exactly by the same workgroup (dense_shade_block, vrt_dense_block.hpp), as are blocks with more than 2048
+// survivors or a sample range of more than 8 x 376 nodes.  The bound is a worst case (every kink at its worst phase,
 // all errors aligned): measured deviations are 20-30 x smaller.
 //
 // Work split: 16 waves hold the same 64 rays (lane = ray).  Wave w owns the contiguous nodes [w NT, (w+1) NT): an absorber
@@ -168,6 +168,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
     }
     const uint32_t *dense_queue = C.dense_is_sorted ? C.dense_sorted : C.dense;
     uint32_t n_skip = 0; // (absorber, wave) visits the saturation test settled with one add (statistics)
+    DenseVisits visits;  // ... and what the exact fallback's saturation tests decided
 
     for (;;) {
         __syncthreads(); // everyone is done with the previous item's LDS
@@ -523,22 +524,31 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             }
         }
         if (!ok) { // wave-uniform and the same in every wave
-            if (tid == 0) {
-                C.overflow2[atomicAdd(C.n_overflow2, 1u)] = (cell << 4) | bi;
-                if (O.stats) atomicAdd(&O.stats[19], 1ull);
-            }
+            // Declined: the block is shaded EXACTLY by this very workgroup, with the exact dense kernel's body in the table's LDS (round 4;
+            // rounds 1-3 queued it for an exact launch behind this one -- a launch every frame of a moving camera paid although nothing
+            // was ever in that queue).  Which arithmetic shades a block is still a function of the block alone.
+            if (O.stats && tid == 0) atomicAdd(&O.stats[19], 1ull);
+            __syncthreads(); // everyone is done with the table's LDS
+            static_assert(sizeof(DenseLds<TB_DW>) <= sizeof(TableLds), "the exact fallback works in the table's LDS");
+            dense_shade_block<EXP, ERF, 6, TB_DW, true>(S, T, C, R, O, *reinterpret_cast<DenseLds<TB_DW> *>(&lds),
+                                                        C.scratch + (size_t)blockIdx.x * C.cstride, cell, bi, false, visits);
             continue;
         }
     }
-    if (O.stats && lane == 0) atomicAdd(&O.stats[18], (unsigned long long)n_skip);
+    if (O.stats && lane == 0) {
+        atomicAdd(&O.stats[18], (unsigned long long)n_skip);
+        atomicAdd(&O.stats[13], (unsigned long long)visits.full); atomicAdd(&O.stats[14], (unsigned long long)visits.zero);
+        atomicAdd(&O.stats[15], (unsigned long long)visits.common);
+    }
 }
 
 template <int EXP, int ERF>
-__global__ __launch_bounds__(1024) void render_table_kernel(SceneTables S, TileLists T, CellGrid C, RayGen R, RenderTarget O)
+__global__ __launch_bounds__(1024) void render_table_kernel(RenderArgs) // read through kernel_args<>: vrt_kernels_common.hpp
 {
-    render_table_body<EXP, ERF>(S, T, C, R, O);
+    const RenderArgs &a = kernel_args<RenderArgs>();
+    render_table_body<EXP, ERF>(a.S, a.T, a.C, a.R, a.O);
 }
-// several frames per launch: blockIdx.y is the frame; C2 is the frame's second queue (what the table kernel declines)
+// several frames per launch: blockIdx.y is the frame
 template <int EXP, int ERF>
 __global__ __launch_bounds__(1024) void render_table_batch_kernel(const FrameArgs *__restrict__ frames)
 {
@@ -560,7 +570,7 @@ static void launch_render_table_t(const SceneTables &s, const TileLists &t, cons
                                   const RenderTarget &o, uint32_t grid, hipStream_t st)
 {
     if (grid == 0) return;
-    hipLaunchKernelGGL((render_table_kernel<EXP, ERF>), dim3(grid), dim3(1024), 0, st, s, t, c, r, o);
+    hipLaunchKernelGGL((render_table_kernel<EXP, ERF>), dim3(grid), dim3(1024), 0, st, RenderArgs{ s, t, c, r, o });
 }
 void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
@@ -572,7 +582,7 @@ static void launch_render_table_only_batch_t(const FrameArgs *d_frames, uint32_t
 {
     if (nframes && grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF>), dim3(grid, nframes), dim3(1024), 0, st, d_frames);
 }
-void launch_render_table_only_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
     VRT_DISPATCH_TABLE(launch_render_table_only_batch_t, d_frames, nframes, grid, st);
 }

@@ -3,7 +3,7 @@ kernel (backward branches) and lists, per loop that holds erf terms (v_rcp_f32) 
 instruction count and its scratch loads / stores.  Round-1 verdict: "render_dense_kernel spills 9 VGPRs to scratch --
 nobody checked whether the spill code sits in the absorber loop".
 
-    python tools/spill_sites.py [mangled-name substring] > profiles/rNN_dense_spills.txt
+    python tools/spill_sites.py [mangled-name substring] [translation unit] > profiles/rNN_dense_spills.txt
 """
 import os
 import re
@@ -13,11 +13,14 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 want = sys.argv[1] if len(sys.argv) > 1 else "render_dense_kernelILi1ELi1ELi6ELi16ELb1"
-src = os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "csrc", "vrt_kernels.hip")
+# the kernel's translation unit: vrt_kernels.hip (exact dense kernel, list kernels), vrt_table_kernel.hip, vrt_block_kernel.hip
+unit = sys.argv[2] if len(sys.argv) > 2 else "vrt_kernels.hip"
+src = os.path.join(ROOT, "simd-gaussian-ray-tracing_amd", "csrc", unit)
+extra = ["-DVRT_RENDER_ECMAX=6", "-DVRT_RENDER_WPE=3", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] if "block" in unit else []
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-Wno-pass-failed",
-                    "-S", "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+                    "-S", "--cuda-device-only", "-o", out, src] + extra, check=True, stderr=subprocess.DEVNULL)
     s = open(out).read()
 m = re.search(r"^(\S*%s\S*):\s*(;.*)?$" % re.escape(want), s, re.M)
 name = m.group(1)
