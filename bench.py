@@ -480,6 +480,7 @@ def main():
     r.enable_kernel_timing(3)
     t0 = time.perf_counter()
     run(args.steps)
+    t_enqueued = time.perf_counter() - t0      # the host's share: all K steps are enqueued (the GPU may be far behind, or waiting)
     barrier()
     elapsed = time.perf_counter() - t0
     if os.environ.get("VRT_BENCH_DEBUG") and not solo:
@@ -721,6 +722,8 @@ def main():
             # context, measured after the timed region); ms_per_step is the timed loop's wall time per step, which with
             # several frames in flight is a throughput figure
             "ms_per_frame": serial_ms if solo else ms_per_step,
+            # how long the host took to ENQUEUE the K timed steps (rank 0): where this approaches ms_per_step the loop is host-bound
+            "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if (solo and world > 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"-g {args.grid} -w {w} (tiles {args.tiles}, mode-8 packing, cull_eps {args.cull_eps:g}, ray-level prune {args.cull_prune:g}, "
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",

@@ -314,20 +314,9 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         const uint32_t *list = C.indices + (size_t)cell * C.cstride;
         if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
 
-        // The first 64 candidates' rows are requested BEFORE the ray set-up (round 4): queue entry -> list -> rows is the longest wait
-        // of a block, at the start of a launch every wave walks it at the same time, and the ~250 instructions of ray generation and
-        // cone fit behind the two round trips instead of in front of them.
-        const bool have0 = lane < n_list;
-        const uint32_t idx0 = have0 ? list[lane] : 0u;
-
         LaneRay ray = pixel_ray(R, pix);
         // the origin is wave-uniform (SGPRs): as a VGPR operand the 15 adds per emitter of the emission issue at full rate
         ray.ox = pin_vgpr(ray.ox); ray.oy = pin_vgpr(ray.oy); ray.oz = pin_vgpr(ray.oz);
-
-        float4 a0, bq0, ms0, alb0;
-        float q0 = 0.f;
-        a0 = bq0 = ms0 = alb0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (have0) { a0 = S.gA[idx0]; bq0 = S.gB[idx0]; ms0 = S.mu_sig[idx0]; alb0 = S.gC[idx0]; q0 = S.gD[idx0].y; }
 
         // ---- block cone: axis = mean of the four centre rays, angle = farthest lane ----
         float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
@@ -351,10 +340,13 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             float4 a, bq, ms, alb;
             float q;
             if (k < n_list) {
-                if (base == 0) { a = a0; bq = bq0; ms = ms0; alb = alb0; q = q0; }
-                else {
-                    const uint32_t idx = list[k];
-                    a = S.gA[idx]; bq = S.gB[idx]; ms = S.mu_sig[idx]; alb = S.gC[idx]; q = S.gD[idx].y;
+                const uint32_t idx = list[k];
+                bq = S.gB[idx]; ms = S.mu_sig[idx]; alb = S.gC[idx]; q = S.gD[idx].y;
+                // the per-origin row (centre - origin, |.|^2) from the centre itself, in prep_frame_kernel's arithmetic: one 16-B gather
+                // of five less per candidate (round 4; the table S.gA stays for the dense-path kernels)
+                {
+                    const float ocx = ms.x - R.origin[0], ocy = ms.y - R.origin[1], ocz = ms.z - R.origin[2];
+                    a = make_float4(ocx, ocy, ocz, dot3_ref(ocx, ocy, ocz, ocx, ocy, ocz));
                 }
                 keep = cone_keeps(cone, a, make_float4(bq.x, bq.y, bq.z, slack_cull_x(bq.w, slack, T.floor_x)));
             }
