@@ -258,10 +258,11 @@ def main():
     ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
     ap.add_argument("--setup-ms", type=float, default=50.0, help="untimed set-up frames before the warm-up steps, in milliseconds of wall time")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: launch every frame of a gather batch on its own (round-2 baseline)")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
-                    help="N = 1: library contexts (each on its own HIP stream) the frames alternate between; 1 = strictly serial "
-                         "frames; default 4 = one per hardware queue of the HIP runtime, whatever --steps is (round 2 took 3 for "
-                         "short runs; the other counts are measured after the timed region and reported under in_flight_sweep)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="N = 1: library contexts (each on its own HIP stream) the timed frames alternate between; 1 = strictly serial "
+                         "frames; default 2 = double buffering, whatever --steps is (round 4: every context costs a timed region ~30 us "
+                         "of start-up and drain -- 20 steps read 24.5 us per step with two contexts, 26.5 with four -- and the steady "
+                         "state loses 2 %: 21.2 against 20.7 us; 1..4 are measured after the timed region: in_flight_sweep)")
     ap.add_argument("--parallel", choices=["tiles", "frames"], default="tiles",
                     help="N > 1: 'tiles' = one frame's tiles sharded over the ranks + gather (the headline, SURVEY 8e); 'frames' = "
                          "every rank renders whole frames of its own, no collective (the replicas-only alternative: weak scaling)")
@@ -316,8 +317,9 @@ def main():
     # (the frame rate is set by the gather there).
     solo = world == 1 or args.parallel == "frames"   # this rank renders whole frames on its own
     if args.frames_in_flight <= 0:
-        args.frames_in_flight = 4
-    nctx = max(1, args.frames_in_flight) if solo else 1
+        args.frames_in_flight = 2
+    nfl = max(1, args.frames_in_flight) if solo else 1          # frames in flight of the timed region
+    nctx = (max(nfl, 4) if world == 1 else nfl) if solo else 1   # contexts: N = 1 also measures 1..4 in flight after the timed region
 
     def make_renderer():
         r_ = pkg.Renderer(local_rank)
@@ -428,7 +430,7 @@ def main():
             # `image` is written by nothing but this call: retained assembly (only cells that went dark are reset, not 16.8 MB)
             r.scatter_sparse_device([t_.data_ptr() for t_ in fg.gathered_shards(b, f)], pack, img_ptr, sp, retained=True)
 
-    def run(nsteps, in_flight=nctx, serial=False):
+    def run(nsteps, in_flight=nfl, serial=False):
         if solo:
             for k in range(nsteps):
                 i = k % in_flight
@@ -513,14 +515,14 @@ def main():
                 i = k % in_flight
                 mcalls[i][k % 64](img_ptrs[i], sps[i])
 
-        run_moving(64, nctx)
+        run_moving(64, nfl)
         barrier()
         t2 = time.perf_counter()
-        run_moving(n_serial, nctx)
+        run_moving(n_serial, nfl)
         barrier()
         mov_ms = (time.perf_counter() - t2) / n_serial * 1e3
         # the last frame of every context against a fresh render of its pose
-        last = {(k % nctx): k % 64 for k in range(n_serial)}
+        last = {(k % nfl): k % 64 for k in range(n_serial)}
         mov_ok = True
         for i_, k_ in last.items():
             r.set_camera_view(w, h, poses[k_].view)
@@ -532,13 +534,13 @@ def main():
         barrier()
         mov_serial_ms = (time.perf_counter() - t2) / n_serial * 1e3
         moving = {"what": "the view turned by 1e-4 degrees per step: rays, cone table, lists and every launch per frame",
-                  "frames_in_flight": nctx, "ms_per_step": mov_ms, "value": w * h / (mov_ms * 1e-3) / 1e6,
+                  "frames_in_flight": nfl, "ms_per_step": mov_ms, "value": w * h / (mov_ms * 1e-3) / 1e6,
                   "serial_ms_per_frame": mov_serial_ms, "serial_value": w * h / (mov_serial_ms * 1e-3) / 1e6, "steps": n_serial,
                   "frames_equal_reference": mov_ok}
         # back to the static view of the timed region (the statistics pass and the frame check below use it)
         for r_ in ctxs:
             r_.set_camera_view(w, h, view)
-        run(2 * nctx)
+        run(2 * nctx, nctx)
         barrier()
         sweep = {}
         for nf in range(1, nctx + 1):
@@ -548,19 +550,19 @@ def main():
             run(n_serial, nf)
             barrier()
             sweep[str(nf)] = (time.perf_counter() - t2) / n_serial * 1e3
-        run(2 * nctx)   # every frame buffer holds the static frame again
+        run(2 * nctx, nctx)   # every frame buffer holds the static frame again
         barrier()
         # the same loop with the frame buffers declared "retained" (vrt_hip_frame_retained_device: each buffer is written by its
         # context only and still holds its previous frame, like the reference's `image`): the list kernel then resets only the
         # cells that went dark instead of writing 16 MB of background over background.  Reported next to the headline, which
         # keeps the full clear of a caller's buffer.
         rframes = [r_.frame_call(tw, th, view, origin, pack, retained=True) for r_ in ctxs]
-        for k in range(4 * nctx):
-            rframes[k % nctx](img_ptrs[k % nctx], sps[k % nctx])
+        for k in range(4 * nfl):
+            rframes[k % nfl](img_ptrs[k % nfl], sps[k % nfl])
         barrier()
         t2 = time.perf_counter()
         for k in range(n_serial):
-            rframes[k % nctx](img_ptrs[k % nctx], sps[k % nctx])
+            rframes[k % nfl](img_ptrs[k % nfl], sps[k % nfl])
         barrier()
         retained_ms = (time.perf_counter() - t2) / n_serial * 1e3
         t2 = time.perf_counter()
@@ -568,7 +570,7 @@ def main():
             rframes[0](img_ptrs[0], sps[0])
         barrier()
         retained_serial_ms = (time.perf_counter() - t2) / n_serial * 1e3
-        sweep["retained_frame_buffers"] = {"frames_in_flight": nctx, "ms_per_step": retained_ms, "serial_ms_per_frame": retained_serial_ms}
+        sweep["retained_frame_buffers"] = {"frames_in_flight": nfl, "ms_per_step": retained_ms, "serial_ms_per_frame": retained_serial_ms}
     # What the speed costs in accuracy (round-3 verdict): the same loop at EXACT settings -- no budgeted prune, table kernel off
     # (cull_eps stays: its thresholds' share is <= 2.5e-6) -- in flight and serial, after the timed region.
     exact = None
@@ -576,7 +578,7 @@ def main():
         for r_ in ctxs:
             r_.set_cull_prune(0.0)
             r_.set_table_step(0.0)
-        run(8 * nctx)
+        run(8 * nctx, nctx)
         barrier()
         t2 = time.perf_counter()
         run(n_serial)
@@ -588,12 +590,12 @@ def main():
         ex_serial_ms = (time.perf_counter() - t2) / n_serial * 1e3
         _, ex_rad = r.render(origin, pack)
         exact = {"what": "--cull-prune 0 and the table kernel off (vrt_hip_set_table_step(0)); level-wise cull thresholds as timed",
-                 "frames_in_flight": nctx, "ms_per_step": ex_ms, "value": w * h / (ex_ms * 1e-3) / 1e6,
+                 "frames_in_flight": nfl, "ms_per_step": ex_ms, "value": w * h / (ex_ms * 1e-3) / 1e6,
                  "ms_per_frame": ex_serial_ms, "serial_value": w * h / (ex_serial_ms * 1e-3) / 1e6, "steps": n_serial}
         for r_ in ctxs:
             r_.set_cull_prune(args.cull_prune)
             r_.set_table_step(args.table_step)
-        run(4 * nctx)
+        run(4 * nctx, nctx)
         barrier()
     # N > 1: where a rank's time goes -- the timed loop once more with the gatherer's phase timers on (sharding.py: "render" on the
     # batch's render stream, "gather" from enqueue until the frame stream may use it, "assemble" on rank 0), all ranks to rank 0
@@ -736,7 +738,7 @@ def main():
                                            "batches_gathered_twice": fg.regathered}),
                        "frames_per_gather": (None if solo else F),
                        "gather_batches_in_timed_region": (None if solo else (args.steps + F - 1) // F),
-                       "frames_in_flight": nctx,
+                       "frames_in_flight": nfl,
                        "stream_probe_us_per_frame": stream_probe,
                        "frame_equals_single_gpu_frame": frame_ok},
             "roofline": {"bound": "hbm", "achieved": render_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

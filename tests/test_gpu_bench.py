@@ -12,7 +12,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("steps,in_flight", [(20, 4), (40, 4)])
+@pytest.mark.parametrize("steps,in_flight", [(20, 2), (40, 2)])
 def test_bench_line(tmp_path, steps, in_flight):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "3", "--setup-ms", "5"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
@@ -52,7 +52,7 @@ def test_bench_line(tmp_path, steps, in_flight):
     assert abs(m["value"] - 2048 * 2048 / (m["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * m["value"]
     sw = d["in_flight_sweep_ms_per_step"]
     ret = sw.pop("retained_frame_buffers")
-    assert sorted(sw) == [str(k) for k in range(1, in_flight + 1)] and all(0 < t < 0.2 for t in sw.values())
+    assert sorted(sw) == [str(k) for k in range(1, 5)] and all(0 < t < 0.2 for t in sw.values())   # 1..4 in flight, whatever the timed region used
     assert 0 < ret["ms_per_step"] < 0.2 and 0 < ret["serial_ms_per_frame"] < 0.2
     # what the speed costs in accuracy (round-3 verdict): the same loop at exact settings, and the oracle's verdict on the timed frame
     ex = d["exact_settings"]
