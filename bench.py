@@ -319,7 +319,9 @@ def main():
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 2
     nfl = max(1, args.frames_in_flight) if solo else 1          # frames in flight of the timed region
-    nctx = (max(nfl, 4) if world == 1 else nfl) if solo else 1   # contexts: N = 1 also measures 1..4 in flight after the timed region
+    # contexts: N = 1 also measures 1..4 frames in flight after the timed region (--frames-in-flight 1 = a strictly serial process:
+    # one context, nothing ever overlaps -- what the serial rocprofv3 summaries under profiles/ are taken with)
+    nctx = (max(nfl, 4) if (world == 1 and nfl > 1) else nfl) if solo else 1
 
     def make_renderer():
         r_ = pkg.Renderer(local_rank)

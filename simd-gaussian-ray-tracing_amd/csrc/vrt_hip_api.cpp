@@ -1348,6 +1348,9 @@ int vrt_hip_render(vrt_hip_ctx *c, const float origin[3], int pack_flags, uint32
         HIPCHK(c, hipMemcpy(st, c->d_stats.p, sizeof st, hipMemcpyDeviceToHost));
         c->last.table_nodes = st[16]; c->last.table_retries = st[17]; c->last.table_skips = st[18]; c->last.table_declined = st[19]; c->last.table_coarser = st[20]; c->last.table_empty = st[21];
         for (int k = 0; k < 8; ++k) c->last.table_phase_ticks[k] = st[24 + k];
+        if (getenv("VRT_HIP_TABLE_DIAG") && st[7]) // the table phase split by the first wave's clock: staging | node loops | waiting at the chunk barriers (note: [21] is table_empty)
+            fprintf(stderr, "[vrt_hip] table kernel, us per block of its table phase (%.1f): node loops %.1f, waiting at the chunk barriers %.1f, staging the rest (mean over the 16 waves)\n",
+                    st[24 + 5] * 0.01 / st[7], st[22] * 0.01 / 16 / st[7], st[23] * 0.01 / 16 / st[7]);
         c->last.lane_pairs = st[12];
         c->last.dense_visits_full = st[13]; c->last.dense_visits_zero = st[14]; c->last.dense_visits_common = st[15];
         c->last.dense_busy_frac = (st[11] && st[9] > st[8]) ? (double)st[10] / ((double)st[11] * (double)(st[9] - st[8])) : 0.0;

@@ -16,7 +16,7 @@ constexpr int MAX_FUSED_CELLS = 64; // more cells per tile than this: separate c
 #define VRT_PCAP 96
 #endif
 #ifndef VRT_PL
-#define VRT_PL 48
+#define VRT_PL 24
 #endif
 constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four parameter rows + sigma*mag = 68 B each; 96 since round 3 = the dense threshold: a block of
                                   // this kernel never has more)
@@ -25,7 +25,11 @@ constexpr int PCAP = VRT_PCAP;    // per-block candidates cached in LDS (four pa
 #endif
 constexpr int DCAP = VRT_DCAP;        // per-block candidates the dense kernel keeps in LDS (61 KB with the rest; measured: no change below 64 KB, +4 % at 81 KB, +10 % at 104 KB)
 constexpr uint32_t ACTIVE_COUNT_SHIFT = 24, ACTIVE_CELL_MASK = 0xFFFFFFu; // CellGrid::active entries: cell id | min(list length, 255) << 24
-constexpr int PL = VRT_PL;        // per-lane list capacity (u8 positions into the block's candidates)
+constexpr int PL = VRT_PL;        // per-lane list capacity (u8 positions into the block's candidates).  A block with a longer per-ray list goes to the
+                                  // 16-wave kernels.  Round 4: 24, not 48 -- the pair loops are quadratic in the list length and a block is ONE wave here: a
+                                  // block with lists of 40 is 10^5 instructions on a wave that ends up alone on its SIMD, and the launch waits for it
+                                  // (`-f cube.obj` 0.59 -> 0.33 ms per frame, teapot 2048^2 5.83 -> 5.63 ms, monkey 4096^2 12.1 -> 11.8 ms; 16 gains nothing
+                                  // more and costs the far side of the monkey orbit 2 %: gpurun_out/r04, profiles/r04_experiments.md)
 
 // Device-resident scene tables, 16 B rows for 128-bit (scalar) loads.
 struct SceneTables {

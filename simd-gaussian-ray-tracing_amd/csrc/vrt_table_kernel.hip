@@ -28,11 +28,11 @@ namespace vrtk {
 //
 // Work split: 16 waves hold the same 64 rays (lane = ray).  Wave w owns the contiguous nodes [w NT, (w+1) NT): an absorber
 // whose erf is saturated (exactly -1 or +1, erf_saturation<>) over that whole range on all 64 rays costs one add.  The
-// per-(ray, absorber) set-up (A_j, m_j: a dot product, an Exp) is made ONCE per block, 16 absorbers at a time into LDS
-// (wave w stages absorber w of the chunk), instead of by every wave for its own nodes.
+// per-(ray, absorber) set-up (A_j, m_j, E_j: a dot product, an Exp, an Erf) is made ONCE per block instead of by every wave for its
+// own nodes: up to 128 absorbers at a time are staged in the memory of the table itself (wave w stages absorbers w, w + 16, ...),
+// one barrier, and every wave then walks all of them without another one (table_nodes).
 // ---------------------------------------------------------------------------------------------
-constexpr int TB_TC = 2048, TB_GMAX = 384, TB_CH = 16, TB_DW = 16;
-static_assert(TB_CH == TB_DW, "one staged absorber per wave and chunk");
+constexpr int TB_TC = 2048, TB_GMAX = 384, TB_DW = 16, TB_STAGE = 128;
 // Per-kink error bound of the 4-point interpolant, in units of u^2 |A_j| (tools/table_error_study.py verifies the constants
 // for u <= 0.3, all phases): a kink at offset theta in [0, 1) of its node interval moves the interpolant by at most
 //   TB_W0 min(1, 0.28 + 2.58 |theta - 1/2|) u^2 in that interval, TB_W0 theta^2 u^2 in the interval to its right,
@@ -46,14 +46,13 @@ struct TableLds {
         uint32_t hist[TB_GMAX][64];
     };
     uint8_t s3[TB_GMAX][64];                   // 24 KB: kink weight of interval g / S_all in 1/255, rounded up
-    union {                                    // 24 KB
-        struct { float A[2][TB_CH][64], M[2][TB_CH][64], E[2][TB_CH][64]; } st;   // staged set-up, double-buffered
+    union {                                    // 16 KB
         float4 L[TB_DW][64];                                     // partial radiances
         float red[4][TB_DW][64];                                 // partial sums of the range and histogram passes
     };
-    float st_r[2][TB_CH];                      // r_j of the staged absorbers
+    float st_r[TB_STAGE];                      // r_j of the absorbers staged in the table's memory (table_nodes)
 };
-// 152 KB of the 160 KB of LDS a gfx950 CU has (one workgroup per CU): this translation unit is gfx950-only; another ARCH needs a smaller
+// 144 KB of the 160 KB of LDS a gfx950 CU has (one workgroup per CU): this translation unit is gfx950-only; another ARCH needs a smaller
 // TB_GMAX (or a build whose host keeps table_on() false)
 static_assert(sizeof(TableLds) + 512 <= 160 * 1024, "TableLds must fit the 160 KB of LDS of a gfx950 CU");
 
@@ -63,57 +62,50 @@ static_assert(sizeof(TableLds) + 512 <= 160 * 1024, "TableLds must fit the 160 K
 template <int EXP, int ERF, int NT>
 __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds, uint32_t cnt, const LaneRay &ray,
                                             float s_first /* node g0 of this lane */, float h, uint32_t g0, uint32_t wave,
-                                            uint32_t lane, uint32_t &n_skip)
+                                            uint32_t lane, uint32_t &n_skip, unsigned long long *diag /* nullable: statistics runs */)
 {
+    // diagnostics (statistics runs, every wave's clock; stats words 22, 23): ticks in the node loops and waiting at the chunk barriers
+    unsigned long long d_stage = 0, d_loop = 0, d_wait = 0, d_t = diag ? wall_clock64() : 0ull;
+    auto lap = [&](unsigned long long &acc) { if (diag) { const unsigned long long t = wall_clock64(); acc += t - d_t; d_t = t; } };
     constexpr float SAT_M = erf_saturation<ERF>() + 1e-3f;
     const ErfEval<ERF> erf;
     float acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
     float common = 0.f;
-    // Staging: wave w computes (A, m, E) of absorber w of a chunk for its 64 rays.  The absorber's two parameter rows come by
-    // wave-uniform loads issued one chunk AHEAD of their use (fetch(c + 2) before the node loop of chunk c): their latency --
-    // the longest single wait of a small block -- hides behind the erf terms.
-    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
-    bool pv = false;
-    auto fetch = [&](uint32_t chunk) {
-        const uint32_t j = chunk * TB_CH + wave;
-        pv = j < cnt; // wave-uniform
-        if (pv) {
-            const uint32_t idx = __builtin_amdgcn_readfirstlane(lds.idx[j]);
-            pa = uload(S.gA, idx); pb = uload(S.gB, idx);
-        }
-    };
-    auto stage = [&](uint32_t chunk) { // from the rows fetched last
-        const uint32_t b = chunk & 1u;
-        float A = 0.f, m = 0.f, r = 0.f, E = 0.f;
-        if (pv) {
+    // Staging (round 4): the per-(ray, absorber) values (A, m, E) of up to TB_STAGE = 128 absorbers at a time go into the memory of the
+    // TABLE itself -- it is written only at the end of this function, and until then its 96 KB are free: three [128][64] float arrays.
+    // Wave w stages absorbers w, w + 16, ... of the group, one barrier, then every wave walks the whole group without another barrier.
+    // Rounds 1-3 staged 16 absorbers at a time (double-buffered, a barrier per 16): the waves of a SIMD do not run in step -- the
+    // arbiter favours the oldest -- so every barrier had early finishers idling while a lone wave issued at half the SIMD's rate:
+    // a third of the table phase was spent waiting at chunk barriers (mean over the 16 waves, `VRT_HIP_TABLE_DIAG`).  Same values, same
+    // order of summation: bit-identical tables.
+    static_assert(TB_GMAX * 64 == 3 * TB_STAGE * 64, "three staging arrays fill the table exactly");
+    float(*stA)[64] = reinterpret_cast<float(*)[64]>(&lds.tab[0][0]);
+    float(*stM)[64] = stA + TB_STAGE;
+    float(*stE)[64] = stM + TB_STAGE;
+    for (uint32_t base = 0; base < cnt; base += TB_STAGE) {
+        const uint32_t nb = min((uint32_t)TB_STAGE, cnt - base);
+        // (rows by wave-uniform loads, the next absorber's requested before this one's arithmetic)
+        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nbq = na;
+        if (wave < nb) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[base + wave]); na = uload(S.gA, i0_); nbq = uload(S.gB, i0_); }
+        for (uint32_t jj = wave; jj < nb; jj += TB_DW) {
+            const float4 pa = na, pb = nbq;
+            if (jj + TB_DW < nb) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[base + jj + TB_DW]); na = uload(S.gA, in_); nbq = uload(S.gB, in_); }
             const float mubar = dot3_ref(pa.x, pa.y, pa.z, ray.nx, ray.ny, ray.nz);
             const float d2 = sub_ref(pa.w, mul_ref(mubar, mubar));
-            A = pb.z * vexp<EXP>(-(d2 * pb.y));
-            m = mubar * pb.x;
-            E = erf(-m);
-            r = pb.x;
+            const float m = mubar * pb.x;
+            stA[jj][lane] = pb.z * vexp<EXP>(-(d2 * pb.y)); stM[jj][lane] = m; stE[jj][lane] = erf(-m);
+            if (lane == 0) lds.st_r[jj] = pb.x;
         }
-        lds.st.A[b][wave][lane] = A; lds.st.M[b][wave][lane] = m; lds.st.E[b][wave][lane] = E;
-        if (lane == 0) lds.st_r[b][wave] = r;
-    };
-    const uint32_t chunks = (cnt + TB_CH - 1) / TB_CH;
-    fetch(0);
-    stage(0);
-    if (chunks > 1) fetch(1);
-    __syncthreads();
-    for (uint32_t c = 0; c < chunks; ++c) {
-        if (c + 1 < chunks) {
-            stage(c + 1);
-            if (c + 2 < chunks) fetch(c + 2);
-        }
-        const uint32_t b = c & 1u, nj = min((uint32_t)TB_CH, cnt - c * TB_CH);
+        lap(d_stage);
+        __syncthreads();
+        lap(d_wait);
         // the next absorber's staged values are requested one iteration ahead (LDS latency behind the erf terms)
-        float nA = lds.st.A[b][0][lane], nM = lds.st.M[b][0][lane], nE = lds.st.E[b][0][lane], nR = lds.st_r[b][0];
-        for (uint32_t jj = 0; jj < nj; ++jj) {
+        float nA = stA[0][lane], nM = stM[0][lane], nE = stE[0][lane], nR = lds.st_r[0];
+        for (uint32_t jj = 0; jj < nb; ++jj) {
             const float A = nA, m = nM, E = nE, r = nR;
-            if (jj + 1 < nj) { nA = lds.st.A[b][jj + 1][lane]; nM = lds.st.M[b][jj + 1][lane]; nE = lds.st.E[b][jj + 1][lane]; nR = lds.st_r[b][jj + 1]; }
+            if (jj + 1 < nb) { nA = stA[jj + 1][lane]; nM = stM[jj + 1][lane]; nE = stE[jj + 1][lane]; nR = lds.st_r[jj + 1]; }
             const float hr = h * r;
             const float x0 = __builtin_fmaf(s_first, r, -m), x1 = __builtin_fmaf((float)(NT - 1), hr, x0);
             // Four wave-uniform questions about the argument range [x0, x1] of this wave's nodes on all rays, asked together (one
@@ -143,8 +135,11 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
             }
         }
-        __syncthreads(); // chunk c+1 is staged, and everyone is done with buffer b (chunk c+2 goes there)
+        lap(d_loop);
+        __syncthreads(); // everyone is done with the staged values: the next group, or the table itself, goes into their memory
+        lap(d_wait);
     }
+    if (diag && lane == 0) { atomicAdd(&diag[0], d_loop); atomicAdd(&diag[1], d_wait); } // summed over the 16 waves (staging = the rest of the table phase)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         if (g0 + t < (uint32_t)TB_GMAX) lds.tab[g0 + t][lane] = acc[t] + common;
@@ -418,13 +413,13 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 // ---- table: wave w evaluates the nodes [w NT, (w+1) NT) of the segment against all survivors ----
                 const float s_first = __builtin_fmaf(node0 + (float)g0, h, lo);
                 switch (NTsel) {
-                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
-                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
-                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
-                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
-                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
-                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
-                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip); break;
+                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
                 }
                 __syncthreads();
                 stamp(5);
