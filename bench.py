@@ -255,6 +255,9 @@ def main():
     ap.add_argument("--parity-pixels", type=int, default=256, help="lit pixels the oracle checks after the timed region (N = 1; with --no-cpu-baseline: none)")
     ap.add_argument("--cull-prune", type=float, default=6.0, help="budget factor of the block kernel's ray-level prune (library default 6; 0 = off)")
     ap.add_argument("--gather-frames", type=int, default=32, help="N > 1: frames per RCCL gather (one collective per batch)")
+    ap.add_argument("--exchange", choices=["all_gather", "gather"], default="all_gather",
+                    help="N > 1: the collective of a batch -- all_gather (one RCCL launch per batch: the cell counts travel with the data) "
+                         "or gather to rank 0 + a 1-element all-reduce per batch (rounds 2-3)")
     ap.add_argument("--no-stream-probe", action="store_true", help="take torch's next pool streams as they come (see pick_streams)")
     ap.add_argument("--setup-ms", type=float, default=50.0, help="untimed set-up frames before the warm-up steps, in milliseconds of wall time")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: launch every frame of a gather batch on its own (round-2 baseline)")
@@ -381,7 +384,7 @@ def main():
         # three batches in flight (one being rendered, two travelling / being assembled), each with its own stream:
         # measured on one of 8 shards 4.9-5.1 us per frame, against 6.1 with two and 7.9 with one
         NB = 2 if args.no_batch else 3
-        fg = SparseFrameGatherer(dist, rank, world, words, cap, F, "cuda", stage=backend != "nccl", nbuf=NB)
+        fg = SparseFrameGatherer(dist, rank, world, words, cap, F, "cuda", stage=backend != "nccl", nbuf=NB, exchange=args.exchange)
         sparse_frame = r.frame_sparse_call(tw, th, view, origin, pack)
         shard_ptr = [t_.data_ptr() for t_ in fg.shard]
 
@@ -739,7 +742,7 @@ def main():
                                    f"{'plane arrays' if args.plane_arrays else 'in-kernel rays'})",
                        "gaussians": int(len(g)), "rays_per_frame": w * h, "tile_list_entries": n_entries,
                        "parallelism": (f"whole frames on each of {world} ranks, no collective" if (solo and world > 1) else
-                                       f"tile-shard x{world}" + (f" + RCCL gather of sparse shards to rank 0 every {F} frames" if world > 1 else "")
+                                       f"tile-shard x{world}" + (f" + RCCL {args.exchange} of sparse shards every {F} frames, assembled on rank 0" if world > 1 else "")
                                        + (f", {F} frames per kernel launch" if (world > 1 and not args.no_batch) else "")),
                        "shard_transport": (None if solo else {"format": "sparse: 32x32-px cells that hold something", "bytes_per_frame":
                                            fg.bytes_moved / max(1, fg.frames_moved), "compact_shards_would_be": (world - 1) * w * h * 4 // world,

@@ -219,11 +219,20 @@ class SparseFrameGatherer:
     is finished: if a shard was fuller than the prefix that travelled, the batch is gathered again in full before it is
     assembled) -- the frame loop never waits for the GPU.
 
+    exchange  "all_gather" (default, round 4): ONE collective per batch.  Every rank receives every shard prefix, so every rank sees
+              every shard's header -- the cell counts travel with the data and the per-batch all-reduce is gone (only the very first
+              batch still learns its prefix size that way).  A `-g 64 -w 2048` frame is 0.84 MB at N = 8: the links do not notice that
+              eight ranks receive it instead of one, but a batch is then one RCCL launch instead of two, and a short run (the driver's
+              20 steps are four batches of 17 us of rendering each at N = 8) is bound by exactly those launches.
+              "gather": gather to rank 0 + a 1-element all-reduce(MAX) per batch (rounds 2-3).
+
     words    u32 per shard buffer (vrt_hip_sparse_shard_words(), the same on every rank); cap: its capacity in cells
     """
 
-    def __init__(self, dist, rank, world, words, cap, frames, device, stage=False, nbuf=2):
+    def __init__(self, dist, rank, world, words, cap, frames, device, stage=False, nbuf=2, exchange="all_gather"):
         import torch
+        assert exchange in ("all_gather", "gather")
+        self.exchange, self.side = exchange, None   # side: the stream the received headers are looked at on (all_gather on a GPU)
         self.dist, self.rank, self.world, self.words, self.cap = dist, rank, world, int(words), int(cap)
         self.F, self.stage, self.device = max(1, int(frames)), stage, device
         self.P = sparse_pixel_offset(self.cap)
@@ -298,10 +307,23 @@ class SparseFrameGatherer:
             self.sent[b] = torch.cuda.Event()
             self.sent[b].record()
         self.prefix[b], self.cells_sent[b] = prefix, int(cells)
-        if self.rank == 0:
+        everyone = self.exchange == "all_gather"
+        if self.rank == 0 or everyone:
             self.recv[b] = torch.empty((self.world, nf, prefix), dtype=torch.int32, device=self.device)
+        if self.rank == 0:
             self.bytes_moved += (self.world - 1) * nf * prefix * 4
             self.frames_moved += nf
+        if everyone:
+            if not self.stage:
+                if send.is_cuda:    # recv[b] is the stack of the ranks' (nf, prefix) blocks along its first dimension
+                    return self.dist.all_gather_into_tensor(self.recv[b], send, async_op=True)
+                return self.dist.all_gather(list(self.recv[b].unbind(0)), send, async_op=True)
+            host = send.cpu()
+            out = [torch.empty_like(host) for _ in range(self.world)]
+            self.dist.all_gather(out, host)
+            for q in range(self.world):
+                self.recv[b][q].copy_(out[q])
+            return None
         dst = list(self.recv[b].unbind(0)) if self.rank == 0 else None
         if not self.stage:
             return self.dist.gather(send, dst, dst=0, async_op=True)
@@ -317,6 +339,26 @@ class SparseFrameGatherer:
         import torch
         frames = self.shard[b].view(self.F, self.words)[:nf]
         self._g0[b] = self.mark()
+        if self.exchange == "all_gather" and self.cells_hint is not None and not self.stage:
+            # no all-reduce: every rank will see every shard's header (word 0 = cells stored) in what it receives; the fullest one
+            # is looked at when the batch is finished -- on a side stream that waits for the collective, copied to pinned memory
+            self.most[b] = self.most_ready[b] = None
+            work = self._gather(b, nf, min(self.cap, self.cells_hint + self.cells_hint // 4 + 8))
+            if self.recv[b].is_cuda:
+                if self.side is None:
+                    self.side = torch.cuda.Stream()
+                with torch.cuda.stream(self.side):
+                    work.wait()                                           # (the side stream waits, nobody else)
+                    seen = self.recv[b][:, :, 0].max().reshape(1).to(torch.int64)
+                    host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                    host.copy_(seen, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self.recv[b].record_stream(self.side)
+                self.most[b], self.most_ready[b] = host, ev
+            else:
+                self.most[b] = "headers"                                  # CPU tensors: read them once the collective has been waited for
+            return work
         most = frames[:, 0].max().reshape(1).to(torch.int64)          # cells of the fullest shard of this batch, this rank
         if self.stage:
             most = most.cpu()
@@ -358,7 +400,7 @@ class SparseFrameGatherer:
             if self.most[b] is not None:                              # the deferred check of this batch's prefix
                 if self.most_ready[b] is not None:
                     self.most_ready[b].synchronize()
-                most = int(self.most[b].item())
+                most = int(self.recv[b][:, :, 0].max().item()) if isinstance(self.most[b], str) else int(self.most[b].item())
                 self.most[b] = None
                 self.cells_hint = max(self.cells_hint, most)
                 if most > self.cells_sent[b]:                         # a shard was fuller than what travelled: once more, in full

@@ -125,7 +125,7 @@ def test_batched_frame_loop(world, nsteps, frames_per_gather, tmp_path, pkg):
     assert int(np.load(out)[0]) == nsteps
 
 
-def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather, grow=False):
+def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather, grow=False, exchange="all_gather"):
     """The sparse protocol (sharding.SparseFrameGatherer, what bench.py runs over RCCL for N > 1) on CPU tensors: frames
     whose lit cells move from frame to frame, tiles that are not a multiple of the 32-px cell, more ranks than lit tiles."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -148,7 +148,7 @@ def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather, 
             blob = ((yy - (20 + 9 * k) % h) ** 2 + (xx - (30 + 31 * k) % w) ** 2) < radius ** 2
             return np.where(blob, (np.uint32(0x01000000) + (yy * w + xx + k).astype(np.uint32)), np.uint32(0)).astype(np.uint32)
 
-        fg = sharding.SparseFrameGatherer(dist, rank, world, words, cap, frames_per_gather, "cpu", nbuf=2 if world == 8 else 3)
+        fg = sharding.SparseFrameGatherer(dist, rank, world, words, cap, frames_per_gather, "cpu", nbuf=2 if world == 8 else 3, exchange=exchange)
         which, counter, frames = {}, [0], []
 
         def render(b, f):
@@ -173,12 +173,15 @@ def _sparse_loop_worker(rank, world, port, out_path, nsteps, frames_per_gather, 
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nsteps,frames_per_gather,grow", [(2, 7, 3, False), (3, 5, 2, False), (8, 4, 4, False), (2, 8, 2, True)])
-def test_sparse_shard_frame_loop(world, nsteps, frames_per_gather, grow, tmp_path, pkg):
+@pytest.mark.parametrize("world,nsteps,frames_per_gather,grow,exchange",
+                         [(2, 7, 3, False, "all_gather"), (3, 5, 2, False, "all_gather"), (8, 4, 4, False, "all_gather"), (2, 8, 2, True, "all_gather"),
+                          (3, 8, 2, True, "all_gather"), (2, 7, 3, False, "gather"), (2, 8, 2, True, "gather")])
+def test_sparse_shard_frame_loop(world, nsteps, frames_per_gather, grow, exchange, tmp_path, pkg):
     """grow: the lit area grows from batch to batch faster than the margin on the travelling prefix -- the check that runs
-    one batch late must notice and gather those batches again in full before they are assembled."""
+    one batch late must notice and gather those batches again in full before they are assembled.  exchange: one all_gather per
+    batch (the cell counts are read from the received headers; round 4, the default) or gather + all-reduce (rounds 2-3)."""
     out = str(tmp_path / "n.npy")
-    mp.spawn(_sparse_loop_worker, args=(world, _free_port(), out, nsteps, frames_per_gather, grow), nprocs=world, join=True)
+    mp.spawn(_sparse_loop_worker, args=(world, _free_port(), out, nsteps, frames_per_gather, grow, exchange), nprocs=world, join=True)
     n, moved, dense, regathered = np.load(out)
     assert int(n) == nsteps
     assert moved < dense or grow    # fewer bytes travel than the compact shards would take
