@@ -107,6 +107,10 @@ __device__ __forceinline__ float vexp(float x)
     else return exp_accurate(x);
 }
 
+// two floats in an aligned register pair: the operand of the packed fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 // ---- erf ------------------------------------------------------------------------------------
 
 // Abramowitz-Stegun 7.1.27 (approx.cpp:90-110): sign * (1 - 1/(1 + a0 t + a1 t^2 + a2 t^3 + a3 t^4)^4): 4 fma +

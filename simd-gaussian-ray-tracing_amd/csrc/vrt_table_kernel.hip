@@ -50,90 +50,205 @@ struct TableLds {
         float4 L[TB_DW][64];                                     // partial radiances
         float red[4][TB_DW][64];                                 // partial sums of the range and histogram passes
     };
-    float st_r[TB_STAGE];                      // r_j of the absorbers staged in the table's memory (table_nodes)
+    float st_r[TB_STAGE], st_cmin[TB_STAGE], st_cmax[TB_STAGE]; // per staged absorber (table_nodes): r_j and the range of its argument offset over the 64 rays
 };
 // 144 KB of the 160 KB of LDS a gfx950 CU has (one workgroup per CU): this translation unit is gfx950-only; another ARCH needs a smaller
 // TB_GMAX (or a build whose host keeps table_on() false)
 static_assert(sizeof(TableLds) + 512 <= 160 * 1024, "TableLds must fit the 160 KB of LDS of a gfx950 CU");
 
-// one pass over the survivors for the NT nodes [g0, g0 + NT) of this wave; tab[g] = sum_j A_j (E_j - Erf(x_gj)), summed per term
-// like the exact kernels (C - sum A_j Erf would round at the magnitude of sum |A_j|: 5e-5 of radiance for 1500 wide Gaussians,
-// tests/fuzz_parity.py seed 3 case 6)
+// The rows (gA, gB) of the survivors a wave works on in one pass -- survivors first, first + 16, ... (at most 64 of them) -- fetched with ONE
+// gather, lane i loading the rows of survivor first + 16 i, and handed to the loop iteration by v_readlane_b32.  The passes used to fetch a
+// survivor's rows by scalar loads one iteration ahead; an iteration is 50-100 instructions, a scalar load that misses its cache several
+// hundred cycles, and its counter (lgkmcnt) is also that of the pass's LDS atomics: the fixed phases of a block ran at the latency of a
+// load per survivor (profiles/r04_experiments.md).
+struct WaveRows {
+    float4 a, b;
+    __device__ __forceinline__ void load(const SceneTables &S, const uint32_t *idx /* LDS */, uint32_t first, uint32_t end, uint32_t lane)
+    {
+        a = make_float4(0.f, 0.f, 0.f, 0.f); b = a;
+        const uint32_t j = first + (uint32_t)TB_DW * lane;
+        if (j < end) { const uint32_t id = idx[j]; a = S.gA[id]; b = S.gB[id]; }
+    }
+    static __device__ __forceinline__ float rl(float v, uint32_t i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)i)); }
+    __device__ __forceinline__ float4 A(uint32_t i) const { return make_float4(rl(a.x, i), rl(a.y, i), rl(a.z, i), rl(a.w, i)); }
+    __device__ __forceinline__ float4 B(uint32_t i) const { return make_float4(rl(b.x, i), rl(b.y, i), rl(b.z, i), rl(b.w, i)); }
+    // iterations of the loop over survivors first, first + 16, ... < end (wave-uniform)
+    static __device__ __forceinline__ uint32_t count(uint32_t first, uint32_t end)
+    {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)(first < end ? min(64u, (end - first + (uint32_t)TB_DW - 1u) / (uint32_t)TB_DW) : 0u));
+    }
+};
+
+// acc[k] += A2 * R(X0 + k HR2) for the NT / 2 node pairs of a wave, written THREE pairs abreast: the chains of one pair (argument, four
+// fmas, two squarings, two reciprocals, the sum) are each other's operands, and the scheduler, short of registers at four waves per SIMD,
+// otherwise lays them out one after the other with a wait state between any two packed instructions
+template <int NT, typename Erf>
+__device__ __forceinline__ void pair_terms(const Erf &erf, v2f (&acc)[NT / 2], v2f A2, v2f HR2, v2f X0)
+{
+    constexpr int W = 3;
+#pragma unroll
+    for (int k0 = 0; k0 < NT / 2; k0 += W) {
+        v2f t[W], p[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (k0 + i < NT / 2) { const v2f K = { (float)(k0 + i), (float)(k0 + i) }; t[i] = fma2(K, HR2, X0); }
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) p[i] = fma2((v2f){ erf.c3, erf.c3 }, t[i], (v2f){ erf.c2, erf.c2 });
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) p[i] = fma2(p[i], t[i], (v2f){ erf.c1, erf.c1 });
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) p[i] = fma2(p[i], t[i], (v2f){ erf.c0, erf.c0 });
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) p[i] = fma2(p[i], t[i], (v2f){ 1.0f, 1.0f });
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) p[i] = p[i] * p[i];
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) p[i] = p[i] * p[i];
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) p[i] = (v2f){ __builtin_amdgcn_rcpf(p[i].x), __builtin_amdgcn_rcpf(p[i].y) };
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (k0 + i < NT / 2) acc[k0 + i] = fma2(A2, p[i], acc[k0 + i]);
+    }
+}
+
+// one pass over the survivors for the NT nodes [g0, g0 + NT) of this wave; tab[g] = sum_j A_j (E_j - Erf(x_gj))
+//
+// Round 4, second half: what a wave does with an absorber -- nothing but one add (its Erf is saturated on all of the wave's nodes on all
+// 64 rays), the one-sign form of the term, or the general form -- used to be asked absorber by absorber inside the node loop: four vector
+// compares, their way to the scalar unit, a three-way branch whose arms the register allocator joined with a copy of every accumulator.
+// With the arms compiled in unconditionally the same loop ran 15-25 % faster than with the questions in it (VRT_TABLE_FORCE experiments,
+// profiles/r04_experiments.md).  Now the questions are asked ONCE per wave and group of 64 staged absorbers, with LANE = ABSORBER, from
+// two wave-uniform numbers per absorber that the staging pass leaves in LDS (the smallest and the largest argument offset over the 64
+// rays): five ballots give five bit masks, and five tight loops walk their set bits -- no question, no branch between forms, every
+// accumulator updated in place.  The one-sign loops run on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two nodes per
+// instruction; 26.5 cycles per term against 36.3, tools/ubench/erf_term.hip, profiles/r04_erf_term_packed.txt) and keep
+// A (E -+ 1) out of the node sums (one fma per absorber instead of one add per term).
+//
+// The sums: tab[g] = [sum over the saturated and one-sign absorbers of A (E -+ 1)] + [sum of +-A R(|x_g|)] + [general terms]; the first
+// bracket is common to the wave's nodes.  Rounding is at the magnitude of sum |A_j| (< 60, or the block is shaded exactly) times 2^-24 per
+// addition -- the same order as the rounding of E and Erf themselves (values near 1 with an ulp of 6e-8) in the term-by-term form.
 template <int EXP, int ERF, int NT>
 __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds, uint32_t cnt, const LaneRay &ray,
-                                            float s_first /* node g0 of this lane */, float h, uint32_t g0, uint32_t wave,
-                                            uint32_t lane, uint32_t &n_skip, unsigned long long *diag /* nullable: statistics runs */)
+                                            float s_seg /* node 0 of this segment's table on this lane's ray */, float h, uint32_t g0,
+                                            uint32_t wave, uint32_t lane, uint32_t &n_skip,
+                                            unsigned long long *diag /* nullable: statistics runs */)
 {
-    // diagnostics (statistics runs, every wave's clock; stats words 22, 23): ticks in the node loops and waiting at the chunk barriers
+    // diagnostics (statistics runs, every wave's clock; stats words 22, 23): ticks in the node loops and waiting at the group barriers
     unsigned long long d_stage = 0, d_loop = 0, d_wait = 0, d_t = diag ? wall_clock64() : 0ull;
     auto lap = [&](unsigned long long &acc) { if (diag) { const unsigned long long t = wall_clock64(); acc += t - d_t; d_t = t; } };
     constexpr float SAT_M = erf_saturation<ERF>() + 1e-3f;
+    constexpr bool AS = ERF == VRT_ERF_AS;
     const ErfEval<ERF> erf;
-    float acc[NT];
+    static_assert(NT % 2 == 0, "the nodes of a wave are worked on in pairs");
+    // the wave's nodes in PAIRS (2k, 2k + 1), arguments x_2k = fma(k, 2 h r, x0), x_2k+1 = fma(k, 2 h r, x0 + h r): one definition for the
+    // packed and the scalar form of the term
+    v2f acc[NT / 2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    for (int k = 0; k < NT / 2; ++k) acc[k] = (v2f){ 0.f, 0.f };
     float common = 0.f;
-    // Staging (round 4): the per-(ray, absorber) values (A, m, E) of up to TB_STAGE = 128 absorbers at a time go into the memory of the
-    // TABLE itself -- it is written only at the end of this function, and until then its 96 KB are free: three [128][64] float arrays.
-    // Wave w stages absorbers w, w + 16, ... of the group, one barrier, then every wave walks the whole group without another barrier.
-    // Rounds 1-3 staged 16 absorbers at a time (double-buffered, a barrier per 16): the waves of a SIMD do not run in step -- the
-    // arbiter favours the oldest -- so every barrier had early finishers idling while a lone wave issued at half the SIMD's rate:
-    // a third of the table phase was spent waiting at chunk barriers (mean over the 16 waves, `VRT_HIP_TABLE_DIAG`).  Same values, same
-    // order of summation: bit-identical tables.
+    const float g0h = (float)g0 * h, g1h = g0h + (float)(NT - 1) * h; // the wave's first and last node, from the segment's node 0
+    const float s_first = __builtin_fmaf((float)g0, h, s_seg);        // this lane's position of node g0
+    // Staging: the per-(ray, absorber) values (A, m, E) of up to TB_STAGE = 128 absorbers at a time go into the memory of the TABLE itself
+    // -- it is written only at the end of this function, and until then its 96 KB are free: three [128][64] float arrays.  Wave w stages
+    // absorbers w, w + 16, ... of the group, one barrier, then every wave walks the whole group without another barrier (rounds 1-3
+    // staged 16 at a time, a barrier per 16: the waves of a SIMD do not run in step -- the arbiter favours the oldest -- so every barrier
+    // had early finishers idling).  Per absorber also r and the range [cmin, cmax] over the 64 rays of c = s_seg r - m: the argument of
+    // node g on a ray is c + g h r.
     static_assert(TB_GMAX * 64 == 3 * TB_STAGE * 64, "three staging arrays fill the table exactly");
     float(*stA)[64] = reinterpret_cast<float(*)[64]>(&lds.tab[0][0]);
     float(*stM)[64] = stA + TB_STAGE;
     float(*stE)[64] = stM + TB_STAGE;
     for (uint32_t base = 0; base < cnt; base += TB_STAGE) {
         const uint32_t nb = min((uint32_t)TB_STAGE, cnt - base);
-        // (rows by wave-uniform loads, the next absorber's requested before this one's arithmetic)
-        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nbq = na;
-        if (wave < nb) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[base + wave]); na = uload(S.gA, i0_); nbq = uload(S.gB, i0_); }
-        for (uint32_t jj = wave; jj < nb; jj += TB_DW) {
-            const float4 pa = na, pb = nbq;
-            if (jj + TB_DW < nb) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[base + jj + TB_DW]); na = uload(S.gA, in_); nbq = uload(S.gB, in_); }
+        WaveRows rows;
+        rows.load(S, lds.idx + base, wave, nb, lane);
+        const uint32_t n_it = WaveRows::count(wave, nb);
+        for (uint32_t i = 0; i < n_it; ++i) {
+            const uint32_t jj = wave + (uint32_t)TB_DW * i;
+            const float4 pa = rows.A(i), pb = rows.B(i);
             const float mubar = dot3_ref(pa.x, pa.y, pa.z, ray.nx, ray.ny, ray.nz);
             const float d2 = sub_ref(pa.w, mul_ref(mubar, mubar));
             const float m = mubar * pb.x;
             stA[jj][lane] = pb.z * vexp<EXP>(-(d2 * pb.y)); stM[jj][lane] = m; stE[jj][lane] = erf(-m);
-            if (lane == 0) lds.st_r[jj] = pb.x;
+            const float c = __builtin_fmaf(s_seg, pb.x, -m);
+            const float c_lo = wave_min(c), c_hi = wave_max(c);
+            if (lane == 0) { lds.st_r[jj] = pb.x; lds.st_cmin[jj] = c_lo; lds.st_cmax[jj] = c_hi; }
         }
         lap(d_stage);
         __syncthreads();
         lap(d_wait);
-        // the next absorber's staged values are requested one iteration ahead (LDS latency behind the erf terms)
-        float nA = stA[0][lane], nM = stM[0][lane], nE = stE[0][lane], nR = lds.st_r[0];
-        for (uint32_t jj = 0; jj < nb; ++jj) {
-            const float A = nA, m = nM, E = nE, r = nR;
-            if (jj + 1 < nb) { nA = stA[jj + 1][lane]; nM = stM[jj + 1][lane]; nE = stE[jj + 1][lane]; nR = lds.st_r[jj + 1]; }
-            const float hr = h * r;
-            const float x0 = __builtin_fmaf(s_first, r, -m), x1 = __builtin_fmaf((float)(NT - 1), hr, x0);
-            // Four wave-uniform questions about the argument range [x0, x1] of this wave's nodes on all rays, asked together (one
-            // after the other each would wait for its own vector compare to reach the scalar unit: a quarter of a small block's
-            // node loop): saturated -- Erf = -1 (the absorber lies behind the nodes) or +1 (in front): one fma; or of ONE sign (all
-            // but the absorbers whose kink lies inside the range): Erf = +-(1 - R), so E - Erf = (E - 1) + R or (E + 1) - R -- ten
-            // instructions per term instead of twelve, no sign transfer (v_bfi_b32: 4.3 issue cycles)
-            const bool sat_lo = __all(x1 <= -SAT_M), sat_hi = __all(x0 >= SAT_M);
-            const bool all_pos = ERF == VRT_ERF_AS && __all(x0 >= 0.f), all_neg = ERF == VRT_ERF_AS && __all(x1 <= 0.f);
-            if (sat_lo | sat_hi) {
-                common = __builtin_fmaf(A, sat_lo ? E + 1.f : E - 1.f, common);
-                ++n_skip;
-            } else if (all_pos) {
-                if constexpr (ERF == VRT_ERF_AS) {
-                    const float Em1 = E - 1.f;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Em1 + erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
-                }
-            } else if (all_neg) {
-                if constexpr (ERF == VRT_ERF_AS) {
-                    const float Ep1 = E + 1.f;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, Ep1 - erf.R(__builtin_fmaf((float)t, hr, x0)), acc[t]);
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)t, hr, x0)), acc[t]);
+        for (uint32_t half = 0; half < nb; half += 64) {
+            // ---- the questions, lane = absorber: is Erf saturated (-1: the absorber lies behind the wave's nodes, +1: in front) on all
+            //      nodes and rays?  Is the argument of one sign on all of them (all but the absorbers whose kink lies inside the range)?
+            //      The answers only choose between forms of the same term: an argument that the rounding of the two formulas (here
+            //      c + g h r, below fma(s, r, -m)) puts on the other side of 0 or of the saturation point moves the term by less
+            //      than 1e-7 |A| (Erf is odd and smooth to first order at 0; R(5.5) = 3e-8). ----
+            unsigned long long m_lo, m_hi, m_pos, m_neg, m_gen;
+            {
+                const uint32_t j = half + lane;
+                const bool in = j < nb;
+                const uint32_t jc = in ? j : 0u;
+                const float r_j = lds.st_r[jc], x_lo = __builtin_fmaf(g0h, r_j, lds.st_cmin[jc]), x_hi = __builtin_fmaf(g1h, r_j, lds.st_cmax[jc]);
+#if defined(VRT_TABLE_FORCE)   /* timing experiments only (wrong images): every visit on one form */
+                const bool b_lo = in && VRT_TABLE_FORCE == 3, b_hi = false, b_pos = in && VRT_TABLE_FORCE == 1, b_neg = false;
+#else
+                const bool b_lo = in && x_hi <= -SAT_M, b_hi = in && x_lo >= SAT_M;
+                const bool b_pos = AS && in && !b_hi && x_lo >= 0.f, b_neg = AS && in && !b_lo && !b_pos && x_hi <= 0.f;
+#endif
+                m_lo = __ballot(b_lo); m_hi = __ballot(b_hi); m_pos = __ballot(b_pos); m_neg = __ballot(b_neg);
+                m_gen = __ballot(in && !(b_lo | b_hi | b_pos | b_neg));
             }
+            n_skip += (uint32_t)__popcll(m_lo) + (uint32_t)__popcll(m_hi);
+            // ---- saturated: E - Erf = E + 1 or E - 1 on every node ----
+            auto walk_AE = [&](unsigned long long mask, auto &&body) {
+                if (!mask) return;
+                uint32_t jn = half + (uint32_t)__builtin_ctzll(mask);
+                float nA = stA[jn][lane], nE = stE[jn][lane];
+                while (mask) {
+                    const float A = nA, E = nE;
+                    mask &= mask - 1ull;
+                    if (mask) { jn = half + (uint32_t)__builtin_ctzll(mask); nA = stA[jn][lane]; nE = stE[jn][lane]; }
+                    body(A, E);
+                }
+            };
+            walk_AE(m_lo, [&](float A, float E) { common = __builtin_fmaf(A, E + 1.f, common); });
+            walk_AE(m_hi, [&](float A, float E) { common = __builtin_fmaf(A, E - 1.f, common); });
+            // ---- the other forms: the next absorber's staged values are requested one iteration ahead (LDS latency behind the terms) ----
+            auto walk = [&](unsigned long long mask, auto &&body) {
+                if (!mask) return;
+                uint32_t jn = half + (uint32_t)__builtin_ctzll(mask);
+                float nA = stA[jn][lane], nM = stM[jn][lane], nE = stE[jn][lane], nR = lds.st_r[jn];
+                while (mask) {
+                    const float A = nA, m = nM, E = nE, r = nR;
+                    mask &= mask - 1ull;
+                    if (mask) { jn = half + (uint32_t)__builtin_ctzll(mask); nA = stA[jn][lane]; nM = stM[jn][lane]; nE = stE[jn][lane]; nR = lds.st_r[jn]; }
+                    body(A, m, E, r);
+                }
+            };
+            if constexpr (AS) {
+                // one sign, x >= 0: Erf = 1 - R(x), E - Erf = (E - 1) + R; x <= 0: Erf = -(1 - R(-x)), E - Erf = (E + 1) - R.  |x| without an
+                // |abs| modifier (the packed instructions have none): fma(k, -a, -b) = -fma(k, a, b) exactly, the negations are modifiers.
+                walk(m_pos, [&](float A, float m, float E, float r) {
+                    const float hr = h * r, hr2 = hr + hr, x0 = __builtin_fmaf(s_first, r, -m), x0b = x0 + hr;
+                    const v2f X0 = { x0, x0b }, HR2 = { hr2, hr2 }, A2 = { A, A };
+                    common = __builtin_fmaf(A, E - 1.f, common);
+                    pair_terms<NT>(erf, acc, A2, HR2, X0);
+                });
+                walk(m_neg, [&](float A, float m, float E, float r) {
+                    const float hr = h * r, hr2 = hr + hr, x0 = __builtin_fmaf(s_first, r, -m), x0b = x0 + hr;
+                    const v2f X0 = { -x0, -x0b }, HR2 = { -hr2, -hr2 }, A2 = { -A, -A };
+                    common = __builtin_fmaf(A, E + 1.f, common);
+                    pair_terms<NT>(erf, acc, A2, HR2, X0);
+                });
+            }
+            walk(m_gen, [&](float A, float m, float E, float r) {
+                const float hr = h * r, hr2 = hr + hr, x0 = __builtin_fmaf(s_first, r, -m), x0b = x0 + hr;
+#pragma unroll
+                for (int k = 0; k < NT / 2; ++k) {
+                    acc[k].x = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)k, hr2, x0)), acc[k].x);
+                    acc[k].y = __builtin_fmaf(A, E - erf(__builtin_fmaf((float)k, hr2, x0b)), acc[k].y);
+                }
+            });
         }
         lap(d_loop);
         __syncthreads(); // everyone is done with the staged values: the next group, or the table itself, goes into their memory
@@ -142,7 +257,7 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
     if (diag && lane == 0) { atomicAdd(&diag[0], d_loop); atomicAdd(&diag[1], d_wait); } // summed over the 16 waves (staging = the rest of the table phase)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-        if (g0 + t < (uint32_t)TB_GMAX) lds.tab[g0 + t][lane] = acc[t] + common;
+        if (g0 + t < (uint32_t)TB_GMAX) lds.tab[g0 + t][lane] = ((t & 1) ? acc[t / 2].y : acc[t / 2].x) + common;
 }
 
 template <int EXP, int ERF>
@@ -174,6 +289,9 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
         // phase clock (statistics runs only): thread 0 adds the time since the last stamp to stats[24 + phase]
         unsigned long long t_last = (O.stats && tid == 0) ? wall_clock64() : 0ull;
         auto stamp = [&](int phase) {
+#ifdef VRT_TABLE_FINE   /* diagnostic build: slots 1-4 belong to the inside of kink_pass */
+            if (phase >= 1 && phase <= 4) phase = 0;
+#endif
             if (O.stats && tid == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&O.stats[24 + phase], t - t_last); t_last = t; }
         };
         uint32_t cell, bi;
@@ -249,17 +367,19 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
         bool ok = cnt <= (uint32_t)TC;
         float s_lo = INFINITY, s_hi = -INFINITY, r_max = 0.f;
         if (ok) {
-            // (rows by wave-uniform loads, the next iteration's requested before this one's arithmetic: here and in the passes below)
-            float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
-            if (wave < cnt) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[wave]); na = uload(S.gA, i0_); nb = uload(S.gB, i0_); }
-            for (uint32_t j = wave; j < cnt; j += DW) {
-                const float4 a = na;
-                const float r = nb.x;
-                if (j + DW < cnt) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[j + DW]); na = uload(S.gA, in_); nb = uload(S.gB, in_); }
-                const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
-                s_hi = fmaxf(s_hi, mubar);
-                s_lo = fminf(s_lo, mubar - 2.8285f / r); // mubar - 4 sigma, sigma = 1/(sqrt2 r), rounded outwards
-                r_max = fmaxf(r_max, r);
+            // (the wave's rows by one gather per 1024 survivors: WaveRows; here and in the passes below)
+            for (uint32_t first = wave; first < cnt; first += 64u * DW) {
+                WaveRows rows;
+                rows.load(S, lds.idx, first, cnt, lane);
+                const uint32_t n_it = WaveRows::count(first, cnt);
+                for (uint32_t i = 0; i < n_it; ++i) {
+                    const float4 a = rows.A(i);
+                    const float r = WaveRows::rl(rows.b.x, i);
+                    const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+                    s_hi = fmaxf(s_hi, mubar);
+                    s_lo = fminf(s_lo, mubar - 2.8285f / r); // mubar - 4 sigma, sigma = 1/(sqrt2 r), rounded outwards
+                    r_max = fmaxf(r_max, r);
+                }
             }
             lds.red[0][wave][lane] = s_hi; lds.red[1][wave][lane] = s_lo;
             if (lane == 0) s_rmax[wave] = r_max;
@@ -310,29 +430,40 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             //      and its two neighbours; with `sums` also S_all = sum |A_j| ----
             auto kink_pass = [&](uint32_t seg, bool sums) {
                 const float node0 = (float)(seg * SL) - 2.f; // the segment's first node on the ray's grid
+#ifdef VRT_TABLE_FINE
+                auto fine = [&](int k) { if (O.stats && tid == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&O.stats[24 + k], t - t_last); t_last = t; } };
+#else
+                auto fine = [&](int) {};
+#endif
+                fine(0);
                 for (uint32_t g = wave; g < G; g += DW) lds.hist[g][lane] = 0u;
                 __syncthreads();
+                fine(1);
                 float s_part = 0.f;
-                float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
-                if (wave < cnt) { const uint32_t i0_ = __builtin_amdgcn_readfirstlane(lds.idx[wave]); na = uload(S.gA, i0_); nb = uload(S.gB, i0_); }
-                for (uint32_t j = wave; j < cnt; j += DW) {
-                    const float4 ca = na, cb = nb;
-                    if (j + DW < cnt) { const uint32_t in_ = __builtin_amdgcn_readfirstlane(lds.idx[j + DW]); na = uload(S.gA, in_); nb = uload(S.gB, in_); }
-                    const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
-                    const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
-                    const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
-                    if (sums) s_part += fabsf(A);
-                    const float pos = (mubar - lo) * inv_h;
-                    const float gb = floorf(pos);
-                    const float th = fminf(fmaxf(pos - gb, 0.f), 1.f);
-                    const float a16 = fminf(fabsf(A), 60.f) * 65536.f;
-                    const float gl = gb - node0; // interval of the kink in this segment's table
-                    if (gl >= 0.f && gl < (float)G) atomicAdd(&lds.hist[(uint32_t)gl][lane], (uint32_t)ceilf(a16 * fminf(1.f, 0.28f + 2.58f * fabsf(th - 0.5f))));
-                    if (gl + 1.f >= 0.f && gl + 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl + 1.f)][lane], (uint32_t)ceilf(a16 * th * th));
-                    if (gl - 1.f >= 0.f && gl - 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl - 1.f)][lane], (uint32_t)ceilf(a16 * (1.f - th) * (1.f - th)));
+                for (uint32_t first = wave; first < cnt; first += 64u * DW) {
+                    WaveRows rows;
+                    rows.load(S, lds.idx, first, cnt, lane);
+                    const uint32_t n_it = WaveRows::count(first, cnt);
+                    for (uint32_t i = 0; i < n_it; ++i) {
+                        const float4 ca = rows.A(i), cb = rows.B(i);
+                        const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
+                        const float d2 = sub_ref(ca.w, mul_ref(mubar, mubar));
+                        const float A = cb.z * vexp<EXP>(-(d2 * cb.y));
+                        if (sums) s_part += fabsf(A);
+                        const float pos = (mubar - lo) * inv_h;
+                        const float gb = floorf(pos);
+                        const float th = fminf(fmaxf(pos - gb, 0.f), 1.f);
+                        const float a16 = fminf(fabsf(A), 60.f) * 65536.f;
+                        const float gl = gb - node0; // interval of the kink in this segment's table
+                        if (gl >= 0.f && gl < (float)G) atomicAdd(&lds.hist[(uint32_t)gl][lane], (uint32_t)ceilf(a16 * fminf(1.f, 0.28f + 2.58f * fabsf(th - 0.5f))));
+                        if (gl + 1.f >= 0.f && gl + 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl + 1.f)][lane], (uint32_t)ceilf(a16 * th * th));
+                        if (gl - 1.f >= 0.f && gl - 1.f < (float)G) atomicAdd(&lds.hist[(uint32_t)(gl - 1.f)][lane], (uint32_t)ceilf(a16 * (1.f - th) * (1.f - th)));
+                    }
                 }
+                fine(2);
                 if (sums) lds.red[3][wave][lane] = s_part;
                 __syncthreads();
+                fine(3);
                 if (sums) {
                     S_all = 0.f;
 #pragma unroll
@@ -341,61 +472,78 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             };
 
             // ---- first attempt: how much coarser than requested may the nodes be?  An ESTIMATE of the bound the emission pass
-            //      will find, from the kink weights at the requested spacing: emission of interval g ~ 1.4 D_g T_g with
-            //      D_g = K_g / 1.35 the absorber mass of the interval and T_g = exp(-2 sum of the mass before it); the estimate
-            //      scales with the spacing like kappa^3 (kink part) and kappa^4 (smooth part).  It only picks the spacing: the
-            //      bound itself is checked below, and a block that fails it is redone at 0.6 of the spacing. ----
+            //      will find, from the kink weights: emission of interval g ~ 1.4 D_g T_g with D_g = K_g / 1.35 the absorber mass of
+            //      the interval and T_g = exp(-2 sum of the mass before it); the estimate scales with the spacing like rho^3 (kink
+            //      part) and rho^4 (smooth part).  It only picks the spacing: the bound itself is checked below, and a block that
+            //      fails it is redone at 0.6 of the spacing.
+            //      The weights are taken at the COARSEST spacing the settings and the menu of table sizes allow (rounds 3-4 took them
+            //      at the requested spacing -- two or three segments' passes for a teapot block -- and then again at the chosen one):
+            //      44-48 % of the blocks of the OBJ scenes keep that spacing, and for them these weights are the final ones; the
+            //      others scale the estimate DOWN to the finer candidates. ----
             bool have_kinks = false; // the kink weights of segment 0 at the final spacing are in LDS
             bool have_sums = false;  // S_all is known (it does not depend on the spacing)
             if (attempt == 0 && C.table_adapt > 1.f) {
-                float P = 0.f, pin = 0.f, pout = 0.f;
-                for (uint32_t seg = 0; seg < nseg; ++seg) {
-                    kink_pass(seg, seg == 0);
-                    const uint32_t ga = seg ? 2u : 0u, gz = min(G, SL + 2u); // the segment's own intervals
-                    const uint32_t wa = min(gz, ga + wave * NTsel), wz = min(gz, wa + NTsel);
-                    float mass = 0.f;
-                    for (uint32_t g = wa; g < wz; ++g) mass += (float)lds.hist[g][lane];
-                    lds.red[0][wave][lane] = mass * (1.f / (1.35f * 65536.f));
+                const float h_r = h, u_r = u; // the requested spacing, as the menu of table sizes rounds it
+                const uint32_t nodes_r = nseg * NTsel;
+                auto menu = [](int c) { return c == 0 ? 3.f : c == 1 ? 2.5f : c == 2 ? 2.f : c == 3 ? 1.6f : 1.3f; };
+                float k_max = 1.f;
+#pragma unroll
+                for (int c = 4; c >= 0; --c)
+                    if (menu(c) <= C.table_adapt && menu(c) * u_r <= 0.3f) k_max = menu(c);
+                if (k_max > 1.f && plan(h_r * k_max) && nseg * NTsel < nodes_r) {
+                    const float h_c = h;
+                    float P = 0.f, pin = 0.f, pout = 0.f;
+                    for (uint32_t seg = 0; seg < nseg; ++seg) {
+                        kink_pass(seg, seg == 0);
+                        const uint32_t ga = seg ? 2u : 0u, gz = min(G, SL + 2u); // the segment's own intervals
+                        const uint32_t wa = min(gz, ga + wave * NTsel), wz = min(gz, wa + NTsel);
+                        float mass = 0.f;
+                        for (uint32_t g = wa; g < wz; ++g) mass += (float)lds.hist[g][lane];
+                        lds.red[0][wave][lane] = mass * (1.f / (1.35f * 65536.f));
+                        __syncthreads();
+                        float before = P, total = 0.f;
+#pragma unroll
+                        for (int w = 0; w < DW; ++w) {
+                            const float mw = lds.red[0][w][lane];
+                            before += (uint32_t)w < wave ? mw : 0.f;
+                            total += mw;
+                        }
+                        for (uint32_t g = wa; g < wz; ++g) {
+                            const float Kg = (float)lds.hist[g][lane] * (1.f / 65536.f), D = Kg * (1.f / 1.35f);
+                            const float e = 1.4f * D * __expf(-2.f * before);
+                            pin = __builtin_fmaf(e, Kg, pin); pout += e;
+                            before += D;
+                        }
+                        P += total;
+                        __syncthreads(); // red[0] is rewritten by the next segment
+                    }
+                    have_sums = true;
+                    lds.red[0][wave][lane] = pin; lds.red[1][wave][lane] = pout;
                     __syncthreads();
-                    float before = P, total = 0.f;
+                    float pin_t = 0.f, pout_t = 0.f;
 #pragma unroll
-                    for (int w = 0; w < DW; ++w) {
-                        const float mw = lds.red[0][w][lane];
-                        before += (uint32_t)w < wave ? mw : 0.f;
-                        total += mw;
+                    for (int w = 0; w < DW; ++w) { pin_t += lds.red[0][w][lane]; pout_t += lds.red[1][w][lane]; }
+                    const float est_in = 1.01f * TB_W0 * u * u * pin_t, est_out = 1.01f * TB_COUT * (u * u) * (u * u) * S_all * pout_t;
+                    const float room = C.table_room * C.table_budget;
+                    // the coarsest candidate whose estimate leaves room: k_max itself with the weights as they are (rho = 1), the finer
+                    // ones by scaling; none: the requested spacing
+                    float kappa = 1.f;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const float k = menu(c), rho = k == k_max ? 1.f : h_r * k / h_c;
+                        if (kappa == 1.f && k <= k_max && rho * rho * rho * (est_in + rho * est_out) <= room) kappa = k;
                     }
-                    for (uint32_t g = wa; g < wz; ++g) {
-                        const float Kg = (float)lds.hist[g][lane] * (1.f / 65536.f), D = Kg * (1.f / 1.35f);
-                        const float e = 1.4f * D * __expf(-2.f * before);
-                        pin = __builtin_fmaf(e, Kg, pin); pout += e;
-                        before += D;
+                    kappa = wave_min(valid ? kappa : k_max); // the same in every wave: they hold the same rays
+#ifdef VRT_TABLE_FINE   /* diagnostic build: slot 4 = (sum of 10 kappa) << 32 | blocks that took the coarsest candidate */
+                    if (O.stats && tid == 0) atomicAdd(&O.stats[24 + 4], ((unsigned long long)(kappa * 10.f + 0.5f) << 32) | (kappa == k_max ? 1ull : 0ull));
+#endif
+                    __syncthreads();
+                    if (kappa == k_max) have_kinks = nseg == 1u; // segment 0's weights at this spacing are still in LDS
+                    else if (kappa == 1.f || !plan(h_r * kappa) || nseg * NTsel >= nodes_r) { // (the menu has no smaller table: as requested)
+                        if (!plan(h_target)) { ok = false; break; }
                     }
-                    P += total;
-                    __syncthreads(); // red[0] is rewritten by the next segment
-                }
-                have_sums = true;
-                lds.red[0][wave][lane] = pin; lds.red[1][wave][lane] = pout;
-                __syncthreads();
-                float pin_t = 0.f, pout_t = 0.f;
-#pragma unroll
-                for (int w = 0; w < DW; ++w) { pin_t += lds.red[0][w][lane]; pout_t += lds.red[1][w][lane]; }
-                const float est_in = 1.01f * TB_W0 * u * u * pin_t, est_out = 1.01f * TB_COUT * (u * u) * (u * u) * S_all * pout_t;
-                float kappa = 1.f;
-                const float room = C.table_room * C.table_budget;
-#pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    const float k = c == 0 ? 3.f : c == 1 ? 2.5f : c == 2 ? 2.f : c == 3 ? 1.6f : 1.3f;
-                    if (kappa == 1.f && k <= C.table_adapt && k * u <= 0.3f && k * k * k * (est_in + k * est_out) <= room) kappa = k;
-                }
-                kappa = wave_min(valid ? kappa : 3.f); // the same in every wave: they hold the same rays
-                __syncthreads();
-                const float h_before = h;
-                const uint32_t nodes_before = nseg * NTsel, nseg_before = nseg;
-                if (kappa > 1.f && (!plan(h * kappa) || nseg * NTsel >= nodes_before)) { // the menu has no smaller table: as requested
-                    if (!plan(h_target)) { ok = false; break; }
-                }
-                have_kinks = h == h_before && nseg_before == 1u; // segment 0's weights at this spacing are still in LDS
-                if (O.stats && tid == 0 && h != h_before) atomicAdd(&O.stats[20], 1ull);
+                } else if (!plan(h_target)) { ok = false; break; } // no coarser table to be had: no estimate either
+                if (O.stats && tid == 0 && h != h_r) atomicAdd(&O.stats[20], 1ull);
             }
             stamp(3);
             const uint32_t g0 = wave * NTsel;
@@ -411,15 +559,15 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 stamp(4);
 
                 // ---- table: wave w evaluates the nodes [w NT, (w+1) NT) of the segment against all survivors ----
-                const float s_first = __builtin_fmaf(node0 + (float)g0, h, lo);
+                const float s_seg = __builtin_fmaf(node0, h, lo); // this lane's position of the segment's node 0
                 switch (NTsel) {
-                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_first, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
                 }
                 __syncthreads();
                 stamp(5);
