@@ -1,6 +1,8 @@
 // vrt_table_kernel.hip -- the table kernel: dense blocks through a per-ray table of the transmittance exponent.  A translation unit
 // of its own (the three kernel units compile side by side); the default scheduler (csrc/Makefile has the measurement).
-// gfx950 only: TableLds takes ~152 KB of the CU's 160 KB of LDS (static_assert below).
+// gfx950 only: TableLds takes 145 KB of the CU's 160 KB of LDS (static_assert below).
+// Diagnostic builds (never the product): -DVRT_TABLE_FORCE=1|2|3 sends every (wave, absorber) visit down one form of the term (timing only,
+// wrong images), -DVRT_TABLE_FINE moves the phase clock's slots 1-4 inside the kink pass (profiles/r04_experiments.md).
 #include "vrt_dense_block.hpp"
 
 namespace vrtk {
@@ -27,10 +29,11 @@ namespace vrtk {
 // all errors aligned): measured deviations are 20-30 x smaller.
 //
 // Work split: 16 waves hold the same 64 rays (lane = ray).  Wave w owns the contiguous nodes [w NT, (w+1) NT): an absorber
-// whose erf is saturated (exactly -1 or +1, erf_saturation<>) over that whole range on all 64 rays costs one add.  The
-// per-(ray, absorber) set-up (A_j, m_j, E_j: a dot product, an Exp, an Erf) is made ONCE per block instead of by every wave for its
-// own nodes: up to 128 absorbers at a time are staged in the memory of the table itself (wave w stages absorbers w, w + 16, ...),
-// one barrier, and every wave then walks all of them without another one (table_nodes).
+// whose erf is saturated (-1 or +1, erf_saturation<>) over that whole range on all 64 rays costs one add, one whose argument keeps its
+// sign there runs on the packed fp32 pipe, two nodes per instruction; which of the three it is is asked once per wave and 64 absorbers
+// with lane = absorber (table_nodes).  The per-(ray, absorber) set-up (A_j, m_j, E_j: a dot product, an Exp, an Erf) is made ONCE per
+// block instead of by every wave for its own nodes: up to 128 absorbers at a time are staged in the memory of the table itself (wave w
+// stages absorbers w, w + 16, ...), one barrier, and every wave then walks all of them without another one.
 // ---------------------------------------------------------------------------------------------
 constexpr int TB_TC = 2048, TB_GMAX = 384, TB_DW = 16, TB_STAGE = 128;
 // Per-kink error bound of the 4-point interpolant, in units of u^2 |A_j| (tools/table_error_study.py verifies the constants
@@ -39,8 +42,8 @@ constexpr int TB_TC = 2048, TB_GMAX = 384, TB_DW = 16, TB_STAGE = 128;
 //   TB_W0 (1 - theta)^2 u^2 in the one to its left, and by at most TB_COUT u^4 anywhere else.
 constexpr float TB_W0 = 0.0212f, TB_COUT = 0.36f;
 struct TableLds {
-    uint32_t idx[TB_TC];                       //  8 KB: the block's survivors, in list order (their rows come from the tables by
-                                               //        wave-uniform loads: every pass below needs a row once per wave)
+    uint32_t idx[TB_TC];                       //  8 KB: the block's survivors, in list order (every pass below needs a survivor's rows
+                                               //        once per wave: WaveRows)
     union {                                    // 96 KB: X at node g of lane l; before that the kink weights per interval (fixed point);
         float tab[TB_GMAX][64];                //        after the emission pass the partial error sums
         uint32_t hist[TB_GMAX][64];
@@ -52,15 +55,14 @@ struct TableLds {
     };
     float st_r[TB_STAGE], st_cmin[TB_STAGE], st_cmax[TB_STAGE]; // per staged absorber (table_nodes): r_j and the range of its argument offset over the 64 rays
 };
-// 144 KB of the 160 KB of LDS a gfx950 CU has (one workgroup per CU): this translation unit is gfx950-only; another ARCH needs a smaller
+// 145 KB of the 160 KB of LDS a gfx950 CU has (one workgroup per CU): this translation unit is gfx950-only; another ARCH needs a smaller
 // TB_GMAX (or a build whose host keeps table_on() false)
 static_assert(sizeof(TableLds) + 512 <= 160 * 1024, "TableLds must fit the 160 KB of LDS of a gfx950 CU");
 
 // The rows (gA, gB) of the survivors a wave works on in one pass -- survivors first, first + 16, ... (at most 64 of them) -- fetched with ONE
-// gather, lane i loading the rows of survivor first + 16 i, and handed to the loop iteration by v_readlane_b32.  The passes used to fetch a
-// survivor's rows by scalar loads one iteration ahead; an iteration is 50-100 instructions, a scalar load that misses its cache several
-// hundred cycles, and its counter (lgkmcnt) is also that of the pass's LDS atomics: the fixed phases of a block ran at the latency of a
-// load per survivor (profiles/r04_experiments.md).
+// gather, lane i loading the rows of survivor first + 16 i, and handed to the loop iteration by v_readlane_b32 (the passes used to fetch a
+// survivor's rows by scalar loads one iteration ahead).  Measured neutral (profiles/r04_experiments.md): the fixed phases are not waiting
+// for those loads, they issue ~90 instructions per survivor on four waves per SIMD; kept because the loops lose their lgkmcnt waits.
 struct WaveRows {
     float4 a, b;
     __device__ __forceinline__ void load(const SceneTables &S, const uint32_t *idx /* LDS */, uint32_t first, uint32_t end, uint32_t lane)
