@@ -319,9 +319,9 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
         ray.ox = pin_vgpr(ray.ox); ray.oy = pin_vgpr(ray.oy); ray.oz = pin_vgpr(ray.oz);
 
         // ---- block cone: axis = mean of the four centre rays, angle = farthest lane ----
-        float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
-        float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
-        float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
+        float cx = lane_value(ray.nx, 27) + lane_value(ray.nx, 28) + lane_value(ray.nx, 35) + lane_value(ray.nx, 36);
+        float cy = lane_value(ray.ny, 27) + lane_value(ray.ny, 28) + lane_value(ray.ny, 35) + lane_value(ray.ny, 36);
+        float cz = lane_value(ray.nz, 27) + lane_value(ray.nz, 28) + lane_value(ray.nz, 35) + lane_value(ray.nz, 36);
         {
             const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy + cz * cz);
             cx *= inv; cy *= inv; cz *= inv;
@@ -393,9 +393,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             atomicAdd(&O.stats[1], (unsigned long long)n_list);
             atomicAdd(&O.stats[5], 1ull);
         }
-        uint32_t nmax = nl;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+        uint32_t nmax = wave_max_u32(nl);
         if (C.prune_budget > 0.f && nmax <= PRUNE_PL) {
             switch (nmax) { // exactly as many entries as the block's longest list has, while that is cheap
             case 0: break;
@@ -410,9 +408,7 @@ __device__ __forceinline__ void render_body(const SceneTables &S, const TileList
             case 9: case 10: case 11: case 12: nl = prune_list<12>(s_t, s_lane, nl, lane, C.prune_budget); break;
             default: nl = prune_list<16>(s_t, s_lane, nl, lane, C.prune_budget); break;
             }
-            nmax = nl;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+            nmax = wave_max_u32(nl);
         }
         if (O.stats) {
             unsigned long long tot = nl;

@@ -416,18 +416,13 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
                 if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(m);
                 __syncthreads();
                 const uint32_t v = lane < 16 ? s_wave_cnt[lane] : 0u;
-                uint32_t incl = v;
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-                    if (lane >= (uint32_t)off) incl += up;
-                }
-                const uint32_t before = (uint32_t)__shfl((int)(incl - v), (int)wave, 64);
+                const uint32_t incl = wave_inclusive_sum(v);
+                const uint32_t before = lane_value_u32(incl - v, wave);
                 if (kc) {
                     const uint32_t pos = n_slots + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
                     if (pos < CH_CAP) s_chunk[pos] = c;
                 }
-                n_slots += (uint32_t)__shfl((int)incl, 15, 64);
+                n_slots += lane_value_u32(incl, 15u);
                 __syncthreads();
             }
             if (n_slots > CH_CAP) chunked = false; // (wave-uniform) too many chunks for LDS: every Gaussian is a candidate
@@ -469,23 +464,18 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
         __syncthreads();
         // exclusive prefix over the 64 (sub-pass, wave) counts: one count per lane, wave-level scan
         const uint32_t v = s_wave_cnt[lane];
-        uint32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-            if (lane >= (uint32_t)off) incl += up;
-        }
+        const uint32_t incl = wave_inclusive_sum(v);
         const uint32_t excl = incl - v;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t before = (uint32_t)__shfl((int)excl, u * 16 + (int)wave, 64);
+            const uint32_t before = lane_value_u32(excl, (uint32_t)u * 16u + wave);
             if (keep[u]) {
                 const uint32_t pos = total + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[u], 0));
                 out[pos] = idx[u];
                 if (F.enabled && pos < TCAP) { s_idx[pos] = idx[u]; s_A[pos] = rel(gm[u]); s_B[pos] = gb[u]; }
             }
         }
-        total += (uint32_t)__shfl((int)incl, 63, 64);
+        total += lane_value_u32(incl, 63u);
         __syncthreads();
     }
     const float slack = level_slack(P.cull_ref_n, total); // cell level: the tile's work list enters
@@ -565,8 +555,8 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
             if (nl) base_l = atomicAdd(C.n_light, nl);
             s_base[3] = (uint32_t)__popcll(m_empty);
         }
-        base_a = (uint32_t)__shfl((int)base_a, 0, 64); base_d = (uint32_t)__shfl((int)base_d, 0, 64);
-        base_l = (uint32_t)__shfl((int)base_l, 0, 64);
+        base_a = lane_value_u32(base_a, 0u); base_d = lane_value_u32(base_d, 0u);
+        base_l = lane_value_u32(base_l, 0u);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t cell = lt * cpt + lane;
         if (mine == 1u) {

@@ -39,12 +39,49 @@ __device__ __forceinline__ float4 uload(const float4 *base, uint32_t idx)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// Reductions over the 64 lanes of a FULL wave (every call site is wave-uniform code), on the DPP path of the vector unit: four steps inside
+// the rows of 16 lanes (quad permutes, row_half_mirror, row_mirror), two row broadcasts, one v_readlane_b32 of lane 63.  __shfl_xor is
+// six ds_bpermute_b32 one after the other -- an LDS round trip each, ~1,400 cycles per reduction on the critical path of a block
+// (36 of them per block of the block kernel before round 4).  min / max are order-independent: same bits as before.
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_bits(int v, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));  // quad_perm [1, 0, 3, 2]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));  // quad_perm [2, 3, 0, 1]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false)); // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false)); // row_mirror: every lane holds its row's result
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1 and 3
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ float wave_min(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
+    return __int_as_float(wave_reduce_bits(__float_as_int(v), [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); }));
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    return (uint32_t)wave_reduce_bits((int)v, [](int a, int b) { return (int)max((uint32_t)a, (uint32_t)b); });
+}
+// inclusive prefix sum over the 64 lanes of a full wave on the DPP path: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8 with zeros
+// shifted in), then the row totals by two row broadcasts -- six v_add_u32 with a DPP source instead of six ds_bpermute_b32 in a row
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return (uint32_t)v;
+}
+// lane `l` (wave-uniform at run time, e.g. the wave's number) of a full wave's register
+__device__ __forceinline__ uint32_t lane_value_u32(uint32_t v, uint32_t l)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l));
+}
+// lane `l` (a constant) of a full wave's register, through the scalar unit (__shfl is a ds_bpermute_b32)
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 __device__ __forceinline__ uint32_t pack_pixel(float r, float g, float b, float a, int flags)
 {
@@ -283,9 +320,7 @@ __device__ __forceinline__ Cone make_cone(float cx, float cy, float cz, float mi
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    return __int_as_float(wave_reduce_bits(__float_as_int(v), [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); }));
 }
 // Ray through a pixel for CONE construction only: same geometry as pixel_ray, fast reciprocal square root
 // (shading rays need the reference's exactly rounded normalisation; a cone bound does not).
