@@ -35,13 +35,19 @@ namespace vrtk {
 // block instead of by every wave for its own nodes: up to 128 absorbers at a time are staged in the memory of the table itself (wave w
 // stages absorbers w, w + 16, ...), one barrier, and every wave then walks all of them without another one.
 // ---------------------------------------------------------------------------------------------
-constexpr int TB_TC = 2048, TB_GMAX = 384, TB_DW = 16, TB_STAGE = 128;
+// Sizes per number of waves DW of a workgroup (= of a block: every wave holds the block's 64 rays).  DW = 16: one workgroup per CU, a
+// table of 384 nodes; DW = 8 (round 4): two workgroups per CU, tables of 192 nodes -- blocks with few survivors and short sample
+// ranges spend a third of their time at barriers and in loops of a handful of iterations, which a second workgroup on the CU fills.
+template <int DW>
+struct TableCfg { static constexpr int TC = 2048, GMAX = 24 * DW, STAGE = 8 * DW; };
 // Per-kink error bound of the 4-point interpolant, in units of u^2 |A_j| (tools/table_error_study.py verifies the constants
 // for u <= 0.3, all phases): a kink at offset theta in [0, 1) of its node interval moves the interpolant by at most
 //   TB_W0 min(1, 0.28 + 2.58 |theta - 1/2|) u^2 in that interval, TB_W0 theta^2 u^2 in the interval to its right,
 //   TB_W0 (1 - theta)^2 u^2 in the one to its left, and by at most TB_COUT u^4 anywhere else.
 constexpr float TB_W0 = 0.0212f, TB_COUT = 0.36f;
+template <int DW>
 struct TableLds {
+    static constexpr int TB_TC = TableCfg<DW>::TC, TB_GMAX = TableCfg<DW>::GMAX, TB_STAGE = TableCfg<DW>::STAGE, TB_DW = DW;
     uint32_t idx[TB_TC];                       //  8 KB: the block's survivors, in list order (every pass below needs a survivor's rows
                                                //        once per wave: WaveRows)
     union {                                    // 96 KB: X at node g of lane l; before that the kink weights per interval (fixed point);
@@ -57,12 +63,14 @@ struct TableLds {
 };
 // 145 KB of the 160 KB of LDS a gfx950 CU has (one workgroup per CU): this translation unit is gfx950-only; another ARCH needs a smaller
 // TB_GMAX (or a build whose host keeps table_on() false)
-static_assert(sizeof(TableLds) + 512 <= 160 * 1024, "TableLds must fit the 160 KB of LDS of a gfx950 CU");
+static_assert(sizeof(TableLds<16>) + 512 <= 160 * 1024, "TableLds must fit the 160 KB of LDS of a gfx950 CU");
+static_assert(sizeof(TableLds<8>) + 512 <= 80 * 1024, "two 8-wave workgroups share the 160 KB of LDS of a gfx950 CU");
 
 // The rows (gA, gB) of the survivors a wave works on in one pass -- survivors first, first + 16, ... (at most 64 of them) -- fetched with ONE
 // gather, lane i loading the rows of survivor first + 16 i, and handed to the loop iteration by v_readlane_b32 (the passes used to fetch a
 // survivor's rows by scalar loads one iteration ahead).  Measured neutral (profiles/r04_experiments.md): the fixed phases are not waiting
 // for those loads, they issue ~90 instructions per survivor on four waves per SIMD; kept because the loops lose their lgkmcnt waits.
+template <int TB_DW>
 struct WaveRows {
     float4 a, b;
     __device__ __forceinline__ void load(const SceneTables &S, const uint32_t *idx /* LDS */, uint32_t first, uint32_t end, uint32_t lane)
@@ -129,8 +137,8 @@ __device__ __forceinline__ void pair_terms(const Erf &erf, v2f (&acc)[NT / 2], v
 // The sums: tab[g] = [sum over the saturated and one-sign absorbers of A (E -+ 1)] + [sum of +-A R(|x_g|)] + [general terms]; the first
 // bracket is common to the wave's nodes.  Rounding is at the magnitude of sum |A_j| (< 60, or the block is shaded exactly) times 2^-24 per
 // addition -- the same order as the rounding of E and Erf themselves (values near 1 with an ulp of 6e-8) in the term-by-term form.
-template <int EXP, int ERF, int NT>
-__device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds, uint32_t cnt, const LaneRay &ray,
+template <int EXP, int ERF, int NT, int TB_DW>
+__device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds<TB_DW> &lds, uint32_t cnt, const LaneRay &ray,
                                             float s_seg /* node 0 of this segment's table on this lane's ray */, float h, uint32_t g0,
                                             uint32_t wave, uint32_t lane, uint32_t &n_skip,
                                             unsigned long long *diag /* nullable: statistics runs */)
@@ -140,6 +148,7 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
     auto lap = [&](unsigned long long &acc) { if (diag) { const unsigned long long t = wall_clock64(); acc += t - d_t; d_t = t; } };
     constexpr float SAT_M = erf_saturation<ERF>() + 1e-3f;
     constexpr bool AS = ERF == VRT_ERF_AS;
+    constexpr int TB_GMAX = TableCfg<TB_DW>::GMAX, TB_STAGE = TableCfg<TB_DW>::STAGE;
     const ErfEval<ERF> erf;
     static_assert(NT % 2 == 0, "the nodes of a wave are worked on in pairs");
     // the wave's nodes in PAIRS (2k, 2k + 1), arguments x_2k = fma(k, 2 h r, x0), x_2k+1 = fma(k, 2 h r, x0 + h r): one definition for the
@@ -162,9 +171,9 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
     float(*stE)[64] = stM + TB_STAGE;
     for (uint32_t base = 0; base < cnt; base += TB_STAGE) {
         const uint32_t nb = min((uint32_t)TB_STAGE, cnt - base);
-        WaveRows rows;
+        WaveRows<TB_DW> rows;
         rows.load(S, lds.idx + base, wave, nb, lane);
-        const uint32_t n_it = WaveRows::count(wave, nb);
+        const uint32_t n_it = WaveRows<TB_DW>::count(wave, nb);
         for (uint32_t i = 0; i < n_it; ++i) {
             const uint32_t jj = wave + (uint32_t)TB_DW * i;
             const float4 pa = rows.A(i), pb = rows.B(i);
@@ -262,12 +271,12 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds &lds,
         if (g0 + t < (uint32_t)TB_GMAX) lds.tab[g0 + t][lane] = ((t & 1) ? acc[t / 2].y : acc[t / 2].x) + common;
 }
 
-template <int EXP, int ERF>
+template <int EXP, int ERF, int DW>
 __device__ __forceinline__ void render_table_body(const SceneTables &S, const TileLists &T, const CellGrid &C, const RayGen &R,
                                                   const RenderTarget &O)
 {
-    constexpr int DW = TB_DW, TC = TB_TC;
-    __shared__ TableLds lds;
+    constexpr int TC = TableCfg<DW>::TC, TB_GMAX = TableCfg<DW>::GMAX, TB_DW = DW;
+    __shared__ TableLds<DW> lds;
     __shared__ uint32_t s_wave_cnt[DW];
     __shared__ float s_rmax[DW];
     __shared__ uint32_t s_item, s_flag;
@@ -371,12 +380,12 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
         if (ok) {
             // (the wave's rows by one gather per 1024 survivors: WaveRows; here and in the passes below)
             for (uint32_t first = wave; first < cnt; first += 64u * DW) {
-                WaveRows rows;
+                WaveRows<DW> rows;
                 rows.load(S, lds.idx, first, cnt, lane);
-                const uint32_t n_it = WaveRows::count(first, cnt);
+                const uint32_t n_it = WaveRows<DW>::count(first, cnt);
                 for (uint32_t i = 0; i < n_it; ++i) {
                     const float4 a = rows.A(i);
-                    const float r = WaveRows::rl(rows.b.x, i);
+                    const float r = WaveRows<DW>::rl(rows.b.x, i);
                     const float mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
                     s_hi = fmaxf(s_hi, mubar);
                     s_lo = fminf(s_lo, mubar - 2.8285f / r); // mubar - 4 sigma, sigma = 1/(sqrt2 r), rounded outwards
@@ -443,9 +452,9 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 fine(1);
                 float s_part = 0.f;
                 for (uint32_t first = wave; first < cnt; first += 64u * DW) {
-                    WaveRows rows;
+                    WaveRows<DW> rows;
                     rows.load(S, lds.idx, first, cnt, lane);
-                    const uint32_t n_it = WaveRows::count(first, cnt);
+                    const uint32_t n_it = WaveRows<DW>::count(first, cnt);
                     for (uint32_t i = 0; i < n_it; ++i) {
                         const float4 ca = rows.A(i), cb = rows.B(i);
                         const float mubar = dot3_ref(ca.x, ca.y, ca.z, ray.nx, ray.ny, ray.nz);
@@ -563,13 +572,13 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                 // ---- table: wave w evaluates the nodes [w NT, (w+1) NT) of the segment against all survivors ----
                 const float s_seg = __builtin_fmaf(node0, h, lo); // this lane's position of the segment's node 0
                 switch (NTsel) {
-                case 4: table_nodes<EXP, ERF, 4>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 6: table_nodes<EXP, ERF, 6>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 8: table_nodes<EXP, ERF, 8>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 12: table_nodes<EXP, ERF, 12>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 16: table_nodes<EXP, ERF, 16>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                case 20: table_nodes<EXP, ERF, 20>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
-                default: table_nodes<EXP, ERF, 24>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 4: table_nodes<EXP, ERF, 4, DW>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 6: table_nodes<EXP, ERF, 6, DW>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 8: table_nodes<EXP, ERF, 8, DW>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 12: table_nodes<EXP, ERF, 12, DW>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 16: table_nodes<EXP, ERF, 16, DW>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                case 20: table_nodes<EXP, ERF, 20, DW>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
+                default: table_nodes<EXP, ERF, 24, DW>(S, lds, cnt, ray, s_seg, h, g0, wave, lane, n_skip, O.stats ? O.stats + 22 : nullptr); break;
                 }
                 __syncthreads();
                 stamp(5);
@@ -674,7 +683,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
             // was ever in that queue).  Which arithmetic shades a block is still a function of the block alone.
             if (O.stats && tid == 0) atomicAdd(&O.stats[19], 1ull);
             __syncthreads(); // everyone is done with the table's LDS
-            static_assert(sizeof(DenseLds<TB_DW>) <= sizeof(TableLds), "the exact fallback works in the table's LDS");
+            static_assert(sizeof(DenseLds<TB_DW>) <= sizeof(TableLds<DW>), "the exact fallback works in the table's LDS");
             dense_shade_block<EXP, ERF, 6, TB_DW, true>(S, T, C, R, O, *reinterpret_cast<DenseLds<TB_DW> *>(&lds),
                                                         C.scratch + (size_t)blockIdx.x * C.cstride, cell, bi, false, visits);
             continue;
@@ -687,45 +696,59 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
     }
 }
 
-template <int EXP, int ERF>
-__global__ __launch_bounds__(1024) void render_table_kernel(RenderArgs) // read through kernel_args<>: vrt_kernels_common.hpp
+// (second launch-bounds argument: waves per SIMD the register budget must allow -- 4 = 128 VGPRs, one 16-wave or two 8-wave workgroups per CU)
+template <int EXP, int ERF, int DW>
+__global__ __launch_bounds__(DW * 64, 4) void render_table_kernel(RenderArgs) // read through kernel_args<>: vrt_kernels_common.hpp
 {
     const RenderArgs &a = kernel_args<RenderArgs>();
-    render_table_body<EXP, ERF>(a.S, a.T, a.C, a.R, a.O);
+    render_table_body<EXP, ERF, DW>(a.S, a.T, a.C, a.R, a.O);
 }
 // several frames per launch: blockIdx.y is the frame
-template <int EXP, int ERF>
-__global__ __launch_bounds__(1024) void render_table_batch_kernel(const FrameArgs *__restrict__ frames)
+template <int EXP, int ERF, int DW>
+__global__ __launch_bounds__(DW * 64, 4) void render_table_batch_kernel(const FrameArgs *__restrict__ frames)
 {
     const FrameArgs &a = frames[blockIdx.y];
-    render_table_body<EXP, ERF>(a.S, a.T, a.C, a.R, a.O);
+    render_table_body<EXP, ERF, DW>(a.S, a.T, a.C, a.R, a.O);
+}
+
+// Waves per block: 8 (two workgroups per CU; since round 4).  VRT_HIP_TABLE_WAVES=16 (read once) selects the 16-wave variant of rounds
+// 1-4 for comparison; it exists for the default Exp / Erf pair only.  A setting of the build, not a heuristic: which arithmetic
+// shades a block stays a function of the block alone.
+static int table_waves()
+{
+    static const int w = [] { const char *e = getenv("VRT_HIP_TABLE_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();
+    return w;
 }
 
 // The table kernel's error bound is that of the Abramowitz-Stegun erf (its kink) or of a smoother one (libm); the Exp must
 // be an accurate one (Exp(a)Exp(b) = Exp(a + b)): four pairs are instantiated, the host keeps every other pair exact.
 #define VRT_DISPATCH_TABLE(FN, ...)                                                                \
     switch (exp_kind * 8 + erf_kind) {                                                             \
-    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM>(__VA_ARGS__); break;      \
-    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS>(__VA_ARGS__); break;          \
-    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM>(__VA_ARGS__); break;        \
-    default: FN<VRT_EXP_VCL, VRT_ERF_AS>(__VA_ARGS__); break;                                      \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM, 8>(__VA_ARGS__); break;   \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS, 8>(__VA_ARGS__); break;       \
+    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM, 8>(__VA_ARGS__); break;     \
+    default:                                                                                       \
+        if (table_waves() == 16) FN<VRT_EXP_VCL, VRT_ERF_AS, 16>(__VA_ARGS__);                     \
+        else FN<VRT_EXP_VCL, VRT_ERF_AS, 8>(__VA_ARGS__);                                          \
+        break;                                                                                     \
     }
-template <int EXP, int ERF>
+// `grid` = the number of 16-wave workgroups the host wants (at most one per CU)
+template <int EXP, int ERF, int DW>
 static void launch_render_table_t(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                                   const RenderTarget &o, uint32_t grid, hipStream_t st)
 {
     if (grid == 0) return;
-    hipLaunchKernelGGL((render_table_kernel<EXP, ERF>), dim3(grid), dim3(1024), 0, st, RenderArgs{ s, t, c, r, o });
+    hipLaunchKernelGGL((render_table_kernel<EXP, ERF, DW>), dim3(grid * (16 / DW)), dim3(DW * 64), 0, st, RenderArgs{ s, t, c, r, o });
 }
 void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
     VRT_DISPATCH_TABLE(launch_render_table_t, s, t, c, r, o, grid, st);
 }
-template <int EXP, int ERF>
+template <int EXP, int ERF, int DW>
 static void launch_render_table_only_batch_t(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, hipStream_t st)
 {
-    if (nframes && grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF>), dim3(grid, nframes), dim3(1024), 0, st, d_frames);
+    if (nframes && grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF, DW>), dim3(grid * (16 / DW), nframes), dim3(DW * 64), 0, st, d_frames);
 }
 void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
