@@ -1624,7 +1624,8 @@ int vrt_hip_frame_batch_device(vrt_hip_ctx *const *ctxs, int n, float tw, float 
     for (int i = 0; i < n; ++i) dgrid = std::max(dgrid, ctxs[i]->deferred.dense_grid);
     launch_order_dense_batch(d_rows, rows, (uint32_t)n, st);
     if (table_on(c0))
-        launch_render_table_batch(d_rows, (uint32_t)n, std::min<uint32_t>(dgrid, (uint32_t)c0->num_cus), c0->exp_kind, c0->erf_kind, st);
+        launch_render_table_batch(d_rows, (uint32_t)n, std::min<uint32_t>(dgrid, (uint32_t)c0->num_cus), (uint64_t)rows[0].R.width * rows[0].R.height,
+                                  c0->exp_kind, c0->erf_kind, st);
     else
         launch_render_dense_batch(d_rows, (uint32_t)n, dgrid, c0->dense_waves, c0->exp_kind, c0->erf_kind, st);
     HIPCHK(c0, hipGetLastError());

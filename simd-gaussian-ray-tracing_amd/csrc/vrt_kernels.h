@@ -242,7 +242,8 @@ void launch_render_dense_batch(const FrameArgs *d_frames, uint32_t nframes, uint
 // the per-frame set-up kernels of a batch, one launch each: prep_frame (grid.y = frame), tile_cones, order_dense
 void launch_frame_setup_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st);
 void launch_order_dense_batch(const FrameArgs *d_frames, const FrameArgs *h_frames, uint32_t nframes, hipStream_t st);
-void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st);
+void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint64_t npix /* of a frame: all the same size */,
+                               int exp_kind, int erf_kind, hipStream_t st);
 void launch_assemble(const uint32_t *gathered, uint32_t *image, const uint32_t *tile_of_slot, uint32_t slots_per_rank,
                      uint32_t world, uint64_t rank_stride, const TileLists &t, uint32_t width, uint32_t height, hipStream_t st);
 void launch_iota(uint32_t *p, uint32_t n, hipStream_t st);

@@ -711,26 +711,30 @@ __global__ __launch_bounds__(DW * 64, 4) void render_table_batch_kernel(const Fr
     render_table_body<EXP, ERF, DW>(a.S, a.T, a.C, a.R, a.O);
 }
 
-// Waves per block: 8 (two workgroups per CU; since round 4).  VRT_HIP_TABLE_WAVES=16 (read once) selects the 16-wave variant of rounds
-// 1-4 for comparison; it exists for the default Exp / Erf pair only.  A setting of the build, not a heuristic: which arithmetic
-// shades a block stays a function of the block alone.
-static int table_waves()
+// Waves per block: 8 -- two workgroups per CU -- for frames of at least 2^22 rays (2048^2), 16 for smaller ones.  What decides between
+// them is a block's depth: the 8-wave table holds 184 intervals, so the teapot's blocks (two thin walls far apart: ~260 nodes) need two
+// segments there -- `-f teapot.obj -w 1024` 2.53 against 1.54 ms, at 2048^2 4.57 against 4.73 (-i 90: 6.95 against 6.13) -- while the
+// monkey's (~100-150 nodes) fit: 1.89 against 2.27 ms at 1024^2, 6.25 against 7.77 at 2048^2 from the far side, 21.2 against 22.4 at
+// 4096^2.  The two variants sum in different orders, so the choice must not depend on anything a batch, a shard or a rank sees
+// differently; a block-wise choice would need both shapes in one launch.  It is a function of the FRAME's size alone:
+// small frames are few blocks, and 16 waves finish a block in half the time.  VRT_HIP_TABLE_WAVES = 8 | 16 (read once) forces one variant.
+static int table_waves(uint64_t npix)
 {
-    static const int w = [] { const char *e = getenv("VRT_HIP_TABLE_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();
-    return w;
+    static const int forced = [] { const char *e = getenv("VRT_HIP_TABLE_WAVES"); const int v = e ? atoi(e) : 0; return v == 8 || v == 16 ? v : 0; }();
+    return forced ? forced : (npix >= (1ull << 22) ? 8 : 16);
 }
 
 // The table kernel's error bound is that of the Abramowitz-Stegun erf (its kink) or of a smoother one (libm); the Exp must
 // be an accurate one (Exp(a)Exp(b) = Exp(a + b)): four pairs are instantiated, the host keeps every other pair exact.
+#define VRT_DISPATCH_TABLE_W(FN, E, F, ...)                                                        \
+    if (table_waves(npix) == 8) FN<E, F, 8>(__VA_ARGS__);                                          \
+    else FN<E, F, 16>(__VA_ARGS__)
 #define VRT_DISPATCH_TABLE(FN, ...)                                                                \
     switch (exp_kind * 8 + erf_kind) {                                                             \
-    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: FN<VRT_EXP_LIBM, VRT_ERF_LIBM, 8>(__VA_ARGS__); break;   \
-    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: FN<VRT_EXP_LIBM, VRT_ERF_AS, 8>(__VA_ARGS__); break;       \
-    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: FN<VRT_EXP_VCL, VRT_ERF_LIBM, 8>(__VA_ARGS__); break;     \
-    default:                                                                                       \
-        if (table_waves() == 16) FN<VRT_EXP_VCL, VRT_ERF_AS, 16>(__VA_ARGS__);                     \
-        else FN<VRT_EXP_VCL, VRT_ERF_AS, 8>(__VA_ARGS__);                                          \
-        break;                                                                                     \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_LIBM: VRT_DISPATCH_TABLE_W(FN, VRT_EXP_LIBM, VRT_ERF_LIBM, __VA_ARGS__); break; \
+    case VRT_EXP_LIBM * 8 + VRT_ERF_AS: VRT_DISPATCH_TABLE_W(FN, VRT_EXP_LIBM, VRT_ERF_AS, __VA_ARGS__); break;     \
+    case VRT_EXP_VCL * 8 + VRT_ERF_LIBM: VRT_DISPATCH_TABLE_W(FN, VRT_EXP_VCL, VRT_ERF_LIBM, __VA_ARGS__); break;   \
+    default: VRT_DISPATCH_TABLE_W(FN, VRT_EXP_VCL, VRT_ERF_AS, __VA_ARGS__); break;                \
     }
 // `grid` = the number of 16-wave workgroups the host wants (at most one per CU)
 template <int EXP, int ERF, int DW>
@@ -743,6 +747,7 @@ static void launch_render_table_t(const SceneTables &s, const TileLists &t, cons
 void launch_render_table(const SceneTables &s, const TileLists &t, const CellGrid &c, const RayGen &r,
                          const RenderTarget &o, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
 {
+    const uint64_t npix = (uint64_t)r.width * r.height;
     VRT_DISPATCH_TABLE(launch_render_table_t, s, t, c, r, o, grid, st);
 }
 template <int EXP, int ERF, int DW>
@@ -750,7 +755,7 @@ static void launch_render_table_only_batch_t(const FrameArgs *d_frames, uint32_t
 {
     if (nframes && grid) hipLaunchKernelGGL((render_table_batch_kernel<EXP, ERF, DW>), dim3(grid * (16 / DW), nframes), dim3(DW * 64), 0, st, d_frames);
 }
-void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, int exp_kind, int erf_kind, hipStream_t st)
+void launch_render_table_batch(const FrameArgs *d_frames, uint32_t nframes, uint32_t grid, uint64_t npix, int exp_kind, int erf_kind, hipStream_t st)
 {
     VRT_DISPATCH_TABLE(launch_render_table_only_batch_t, d_frames, nframes, grid, st);
 }
