@@ -601,6 +601,11 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                         const float4 a = cur.a, ms = cur.ms, alb = cur.alb;
                         const float inv2s2 = cur.inv2s2, q = cur.q;
                         const float e_mubar = dot3_ref(a.x, a.y, a.z, ray.nx, ray.ny, ray.nz);
+                        if (nseg > 1u) { // an emitter none of whose samples lies in this segment on any ray adds exact zeros: skipped
+                            const float g_a = floorf((madd_ref(-4.f, ms.w, e_mubar) - lo) * inv_h), g_b = floorf((e_mubar - lo) * inv_h);
+                            const float gi_a = fminf(fmaxf(g_a, 2.f), (float)(Gtot - 4)), gi_b = fminf(fmaxf(g_b, 2.f), (float)(Gtot - 4));
+                            if (!__any(gi_b >= seg_lo && gi_a < seg_hi)) continue;
+                        }
                         float inner = 0.f, inner_abs = 0.f, inner_s3 = 0.f;
 #pragma unroll
                         for (int k = 0; k < 5; ++k) {
