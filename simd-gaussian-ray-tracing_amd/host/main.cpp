@@ -312,29 +312,37 @@ int main(int argc, char **argv)
 
     // An animation whose frames are not written out keeps four frames in flight: the frames alternate between four
     // contexts (each has its own HIP stream), so one frame's list kernel and the tail of its block kernel overlap the
-    // other frames' work (like bench.py).
-    int in_flight = 4; // one per hardware queue of the HIP runtime (VRT_CLI_CONTEXTS=1..8 to try others)
-    if (const char *e = getenv("VRT_CLI_CONTEXTS")) in_flight = std::max(1, std::min(8, atoi(e)));
-    const int nctx = (cmd.outfile == nullptr && cmd.nr_frames > 1 && getenv("VRT_CLI_TRACE") == nullptr) ? in_flight : 1;
+    // other frames' work (like bench.py).  Frames that fill the chip for milliseconds gain nothing from that and lose to the
+    // other frames' workgroups on their CUs (monkey 4096^2 orbit: 19.6 ms per frame on one context, 21.4 on two or four; a teapot
+    // at 512^2, 1.4 ms of a half-empty chip: 1.40 / 0.71 / 0.51): a second untimed frame on the first context decides
+    // (more than 3 ms: one context).  VRT_CLI_CONTEXTS=1..8 fixes the number.  Scheduling only: the images do not depend on it.
+    int in_flight = 4; // one per hardware queue of the HIP runtime
+    const bool fixed_contexts = getenv("VRT_CLI_CONTEXTS") != nullptr;
+    if (fixed_contexts) in_flight = std::max(1, std::min(8, atoi(getenv("VRT_CLI_CONTEXTS"))));
+    int nctx = (cmd.outfile == nullptr && cmd.nr_frames > 1 && getenv("VRT_CLI_TRACE") == nullptr) ? in_flight : 1;
     vrt_hip_ctx *ctxs[8] = {};
     const char *dev = getenv("VRT_HIP_DEVICE");
-    for (int i = 0; i < nctx; ++i)
+    vrt_hip_ctx *ctx = nullptr;
+    auto chk = [&](int rc, const char *what) {
+        if (rc != VRT_HIP_OK) { fprintf(stderr, "[ ERROR ]\t%s: %s\n", what, vrt_hip_last_error(ctx)); exit(EXIT_FAILURE); }
+    };
+    // (all contexts -- their streams -- are created before any work is enqueued: the runtime deals its hardware queues to streams as they
+    // appear, and streams created between another context's copies and launches ended up two to a queue: 0.76 instead of 0.51 ms per
+    // frame for the teapot at 512^2)
+    const int n_created = nctx;
+    for (int i = 0; i < n_created; ++i)
         if (vrt_hip_create(dev ? atoi(dev) : 0, &ctxs[i]) != VRT_HIP_OK) {
             fprintf(stderr, "[ ERROR ]\t%s\n", vrt_hip_last_error(nullptr));
             return EXIT_FAILURE;
         }
-    vrt_hip_ctx *ctx = ctxs[0];
-    auto chk = [&](int rc, const char *what) {
-        if (rc != VRT_HIP_OK) { fprintf(stderr, "[ ERROR ]\t%s: %s\n", what, vrt_hip_last_error(ctx)); exit(EXIT_FAILURE); }
-    };
-    for (int i = 0; i < nctx; ++i) {
+    auto configure = [&](int i) {
         ctx = ctxs[i];
         chk(vrt_hip_set_gaussians_aos(ctx, gaussians.size(), gaussians.data()), "set_gaussians");
         chk(vrt_hip_set_options(ctx, ek, rk, cmd.cull_eps), "set_options");
         chk(vrt_hip_set_table_step(ctx, cmd.table_step), "set_table_step");
         chk(vrt_hip_set_table_budget(ctx, cmd.table_budget), "set_table_budget");
         chk(vrt_hip_set_cull_prune(ctx, cmd.cull_prune), "set_cull_prune");
-    }
+    };
 
     const u64 width = cmd.w, height = cmd.h;
     std::vector<u32> image(width * height);
@@ -352,26 +360,36 @@ int main(int argc, char **argv)
     // The warm-up looks from ANOTHER pose (7 degrees further along the orbit): what the library keeps per camera -- tile cones,
     // per-origin tables, the dense-launch report -- is then not in place for the timed frame, which does a full frame's
     // work like the reference's (round-2 advisor: the warm-up used the timed frame's own pose).
-    if (getenv("VRT_CLI_NO_WARMUP") == nullptr) {
-        vrt::camera_t wcam = cam;
-        wcam.orbit(7.f);
-        wcam.turn(angle - 7.f, 0.f);
-        for (int i = 0; i < nctx; ++i) {
-            ctx = ctxs[i];
-            const f32 origin[3] = { wcam.position[0], wcam.position[1], wcam.position[2] };
-            if (cmd.plane_arrays)
-                chk(vrt_hip_set_plane(ctx, (u32)width, (u32)height, wcam.projection_plane.xs.data(), wcam.projection_plane.ys.data(),
-                                      wcam.projection_plane.zs.data()), "set_plane");
-            else
-                chk(vrt_hip_set_camera_view(ctx, (u32)width, (u32)height, wcam.view_matrix.data()), "set_camera_view");
-            if (use_tiling) {
-                chk(vrt_hip_frame(ctx, 2.f / cmd.tiles, 2.f / cmd.tiles, wcam.view_matrix.data(), origin, pack, nullptr, 1), "frame");
-            } else {
-                chk(vrt_hip_clear_tiles(ctx), "clear_tiles");
-                chk(vrt_hip_render(ctx, origin, pack, nullptr, nullptr), "render");
-            }
+    const bool warm_up = getenv("VRT_CLI_NO_WARMUP") == nullptr;
+    vrt::camera_t wcam = cam;
+    wcam.orbit(7.f);
+    wcam.turn(angle - 7.f, 0.f);
+    auto warm_frame = [&](int i) {
+        ctx = ctxs[i];
+        const f32 origin[3] = { wcam.position[0], wcam.position[1], wcam.position[2] };
+        if (cmd.plane_arrays)
+            chk(vrt_hip_set_plane(ctx, (u32)width, (u32)height, wcam.projection_plane.xs.data(), wcam.projection_plane.ys.data(),
+                                  wcam.projection_plane.zs.data()), "set_plane");
+        else
+            chk(vrt_hip_set_camera_view(ctx, (u32)width, (u32)height, wcam.view_matrix.data()), "set_camera_view");
+        if (use_tiling) {
+            chk(vrt_hip_frame(ctx, 2.f / cmd.tiles, 2.f / cmd.tiles, wcam.view_matrix.data(), origin, pack, nullptr, 1), "frame");
+        } else {
+            chk(vrt_hip_clear_tiles(ctx), "clear_tiles");
+            chk(vrt_hip_render(ctx, origin, pack, nullptr, nullptr), "render");
         }
+    };
+    for (int i = 0; i < n_created; ++i) configure(i);
+    if (warm_up) {
+        warm_frame(0);
+        if (nctx > 1 && !fixed_contexts) { // how long does a frame of this scene take?
+            const double p0 = now_ms();
+            warm_frame(0);
+            if (now_ms() - p0 > 3.0) nctx = 1;
+        }
+        for (int i = 1; i < nctx; ++i) warm_frame(i);
     }
+    ctx = ctxs[0];
 
     f32 total_time = 0.f;
     double t_first = 0.0;
@@ -428,6 +446,6 @@ int main(int argc, char **argv)
         angle -= angle_change;
         cam.turn(angle, 0.f);
     }
-    for (int i = 0; i < nctx; ++i) vrt_hip_destroy(ctxs[i]);
+    for (int i = 0; i < n_created; ++i) vrt_hip_destroy(ctxs[i]);
     return EXIT_SUCCESS;
 }

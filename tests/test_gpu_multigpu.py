@@ -302,12 +302,20 @@ def test_cli_gpus_flag(tmp_path):
         np.testing.assert_array_equal(np.array(Image.open(tmp_path / f"s_{k}.png")), np.array(Image.open(tmp_path / f"m_{k}.png")), err_msg=f"frame {k}")
 
 
+def _free_port():
+    """a port nobody listens on (a fixed one can still be in TIME_WAIT from an earlier run on the same box)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     """bench.py's N = 2 flow (sparse shards -> gather -> scatter on rank 0) with the gloo backend, both ranks on GPU 0:
     the assembled frame must equal the single-GPU frame (bench.py checks it and reports it in its JSON line)."""
     env = dict(os.environ, VRT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",   # what the driver times
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",   # what the driver times
            "--width", "1024", "--no-cpu-baseline"]
     p = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
