@@ -66,16 +66,16 @@ __device__ __forceinline__ void dense_shade_block(const SceneTables &S, const Ti
         if (n_list == 0xFFFFFFFFu) { n_list = T.count[p.t]; list = T.indices + T.start[p.t]; }
 
         const LaneRay ray = pixel_ray(R, pix); // every wave holds the same 64 rays
-        float cx = lane_value(ray.nx, 27) + lane_value(ray.nx, 28) + lane_value(ray.nx, 35) + lane_value(ray.nx, 36);
-        float cy = lane_value(ray.ny, 27) + lane_value(ray.ny, 28) + lane_value(ray.ny, 35) + lane_value(ray.ny, 36);
-        float cz = lane_value(ray.nz, 27) + lane_value(ray.nz, 28) + lane_value(ray.nz, 35) + lane_value(ray.nz, 36);
+        float cx = __shfl(ray.nx, 27, 64) + __shfl(ray.nx, 28, 64) + __shfl(ray.nx, 35, 64) + __shfl(ray.nx, 36, 64);
+        float cy = __shfl(ray.ny, 27, 64) + __shfl(ray.ny, 28, 64) + __shfl(ray.ny, 35, 64) + __shfl(ray.ny, 36, 64);
+        float cz = __shfl(ray.nz, 27, 64) + __shfl(ray.nz, 28, 64) + __shfl(ray.nz, 35, 64) + __shfl(ray.nz, 36, 64);
         {
             const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy + cz * cz);
             cx *= inv; cy *= inv; cz *= inv;
         }
         float co, si;
         cos_sin(ray.nx, ray.ny, ray.nz, cx, cy, cz, co, si);
-        const Cone cone = make_cone(cx, cy, cz, wave_min(co), wave_max(si));
+        const Cone cone = make_cone(cx, cy, cz, wave_min_bpermute(co), wave_max_bpermute(si)); // (not the DPP forms: vrt_kernels_common.hpp)
 
         // ---- cooperative block cull, order preserving across the 16 waves ----
         uint32_t cnt = 0;

@@ -54,6 +54,21 @@ __device__ __forceinline__ int wave_reduce_bits(int v, Op op)
     v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
 }
+// The ds_bpermute_b32 forms (rounds 1-3).  Kept for the exact dense kernel's per-block set-up: with the DPP forms there -- same resource
+// usage, instruction-for-instruction the same hot loops -- render_dense_kernel ran 12 % slower (teapot 2048^2 22.8 -> 25.6 ms, monkey
+// 4096^2 69.0 -> 78.3; profiles/r04_experiments.md); 24 round trips per block are nothing in blocks of milliseconds.
+__device__ __forceinline__ float wave_min_bpermute(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_bpermute(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
 __device__ __forceinline__ float wave_min(float v)
 {
     return __int_as_float(wave_reduce_bits(__float_as_int(v), [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); }));
