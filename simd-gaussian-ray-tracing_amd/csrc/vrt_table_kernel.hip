@@ -45,6 +45,13 @@ struct TableCfg { static constexpr int TC = 2048, GMAX = 24 * DW, STAGE = 8 * DW
 //   TB_W0 min(1, 0.28 + 2.58 |theta - 1/2|) u^2 in that interval, TB_W0 theta^2 u^2 in the interval to its right,
 //   TB_W0 (1 - theta)^2 u^2 in the one to its left, and by at most TB_COUT u^4 anywhere else.
 constexpr float TB_W0 = 0.0212f, TB_COUT = 0.36f;
+// Where the table treats an Erf as +-1 (on all of a wave's nodes and all 64 rays): the Abramowitz-Stegun form reaches exactly +-1 only at
+// |x| = 5.46 -- its tail is 1 / p(|x|)^4, not a Gaussian's -- so an absorber stays "live" over +-5.5 / u nodes.  Cut at 4.5 the tail left
+// out is R(4.5) = 4.31e-7 |A_j| per absorber (libm: erfc(3.5) = 7.43e-7), a step of that size where a saturated wave's nodes meet a live
+// one's (4-point interpolation across a step: at most 1.25 of it): |dX| <= 1.25 R(4.5) S_all everywhere, a term of the bound like the
+// smooth part's 0.36 u^4 S_all -- and a fifth of that at the finest spacing the kernel uses.  18 % fewer live (absorber, node) pairs.
+template <int ERF> __host__ __device__ constexpr float table_saturation() { return ERF == VRT_ERF_AS ? 4.5f : 3.5f; }
+template <int ERF> __host__ __device__ constexpr float table_saturation_eps() { return ERF == VRT_ERF_AS ? 1.25f * 4.31e-7f : 1.25f * 7.44e-7f; }
 template <int DW>
 struct TableLds {
     static constexpr int TB_TC = TableCfg<DW>::TC, TB_GMAX = TableCfg<DW>::GMAX, TB_STAGE = TableCfg<DW>::STAGE, TB_DW = DW;
@@ -146,7 +153,7 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds<TB_DW
     // diagnostics (statistics runs, every wave's clock; stats words 22, 23): ticks in the node loops and waiting at the group barriers
     unsigned long long d_stage = 0, d_loop = 0, d_wait = 0, d_t = diag ? wall_clock64() : 0ull;
     auto lap = [&](unsigned long long &acc) { if (diag) { const unsigned long long t = wall_clock64(); acc += t - d_t; d_t = t; } };
-    constexpr float SAT_M = erf_saturation<ERF>() + 1e-3f;
+    constexpr float SAT_M = table_saturation<ERF>() + 1e-3f;
     constexpr bool AS = ERF == VRT_ERF_AS;
     constexpr int TB_GMAX = TableCfg<TB_DW>::GMAX, TB_STAGE = TableCfg<TB_DW>::STAGE;
     const ErfEval<ERF> erf;
@@ -534,7 +541,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                     float pin_t = 0.f, pout_t = 0.f;
 #pragma unroll
                     for (int w = 0; w < DW; ++w) { pin_t += lds.red[0][w][lane]; pout_t += lds.red[1][w][lane]; }
-                    const float est_in = 1.01f * TB_W0 * u * u * pin_t, est_out = 1.01f * TB_COUT * (u * u) * (u * u) * S_all * pout_t;
+                    const float est_in = 1.01f * TB_W0 * u * u * pin_t, est_out = 1.01f * TB_COUT * (u * u) * (u * u) * S_all * pout_t, est_sat = 1.01f * table_saturation_eps<ERF>() * S_all * pout_t;
                     const float room = C.table_room * C.table_budget;
                     // the coarsest candidate whose estimate leaves room: k_max itself with the weights as they are (rho = 1), the finer
                     // ones by scaling; none: the requested spacing
@@ -542,7 +549,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
                         const float k = menu(c), rho = k == k_max ? 1.f : h_r * k / h_c;
-                        if (kappa == 1.f && k <= k_max && rho * rho * rho * (est_in + rho * est_out) <= room) kappa = k;
+                        if (kappa == 1.f && k <= k_max && rho * rho * rho * (est_in + rho * est_out) + est_sat <= room) kappa = k;
                     }
                     kappa = wave_min(valid ? kappa : k_max); // the same in every wave: they hold the same rays
 #ifdef VRT_TABLE_FINE   /* diagnostic build: slot 4 = (sum of 10 kappa) << 32 | blocks that took the coarsest candidate */
@@ -656,7 +663,7 @@ __device__ __forceinline__ void render_table_body(const SceneTables &S, const Ti
                     bs.x += bv.x; bs.y += bv.y;
                 }
                 // worst-case change of this ray's radiance (header comment); e^dX - 1 <= 1.01 dX for the dX in question
-                const float e_in = TB_W0 * u * u, e_out = TB_COUT * (u * u) * (u * u);
+                const float e_in = TB_W0 * u * u, e_out = TB_COUT * (u * u) * (u * u) + table_saturation_eps<ERF>();
                 const float bound = 1.01f * S_all * (e_in * (1.f / 255.f) * bs.x + e_out * bs.y);
                 // (false for NaN; S_all beyond the fixed-point range of the weights: no bound)
                 const bool good = !valid || (bound <= C.table_budget && S_all < 60.f);
