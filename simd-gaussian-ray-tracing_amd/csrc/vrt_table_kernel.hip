@@ -2,7 +2,8 @@
 // of its own (the three kernel units compile side by side); the default scheduler (csrc/Makefile has the measurement).
 // gfx950 only: TableLds takes 145 KB of the CU's 160 KB of LDS (static_assert below).
 // Diagnostic builds (never the product): -DVRT_TABLE_FORCE=1|2|3 sends every (wave, absorber) visit down one form of the term (timing only,
-// wrong images), -DVRT_TABLE_FINE moves the phase clock's slots 1-4 inside the kink pass (profiles/r04_experiments.md).
+// wrong images), -DVRT_TABLE_FINE moves the phase clock's slots 1-4 inside the kink pass, -DVRT_TABLE_COUNT_CLASSES counts the one-sign and
+// the general visits into the statistics words of VRT_HIP_TABLE_DIAG (profiles/r04_experiments.md).
 #include "vrt_dense_block.hpp"
 
 namespace vrtk {
@@ -152,7 +153,11 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds<TB_DW
 {
     // diagnostics (statistics runs, every wave's clock; stats words 22, 23): ticks in the node loops and waiting at the group barriers
     unsigned long long d_stage = 0, d_loop = 0, d_wait = 0, d_t = diag ? wall_clock64() : 0ull;
+#ifdef VRT_TABLE_COUNT_CLASSES
+    auto lap = [&](unsigned long long &) {};
+#else
     auto lap = [&](unsigned long long &acc) { if (diag) { const unsigned long long t = wall_clock64(); acc += t - d_t; d_t = t; } };
+#endif
     constexpr float SAT_M = table_saturation<ERF>() + 1e-3f;
     constexpr bool AS = ERF == VRT_ERF_AS;
     constexpr int TB_GMAX = TableCfg<TB_DW>::GMAX, TB_STAGE = TableCfg<TB_DW>::STAGE;
@@ -217,6 +222,10 @@ __device__ __forceinline__ void table_nodes(const SceneTables &S, TableLds<TB_DW
                 m_gen = __ballot(in && !(b_lo | b_hi | b_pos | b_neg));
             }
             n_skip += (uint32_t)__popcll(m_lo) + (uint32_t)__popcll(m_hi);
+#ifdef VRT_TABLE_COUNT_CLASSES   /* diagnostic build: stats words 22 / 23 = one-sign / general (wave, absorber) visits instead of the clocks */
+            d_loop += (unsigned long long)__popcll(m_pos) + (unsigned long long)__popcll(m_neg);
+            d_wait += (unsigned long long)__popcll(m_gen);
+#endif
             // ---- saturated: E - Erf = E + 1 or E - 1 on every node ----
             auto walk_AE = [&](unsigned long long mask, auto &&body) {
                 if (!mask) return;
