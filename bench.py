@@ -627,6 +627,53 @@ def main():
         per_rank = [{"rank": int(v[0]), "render_ms_per_frame": float(v[1]), "gather_ms_per_frame_upper_bound": float(v[2]),
                      "gather_collective_ms_per_frame": (float(v[3]) if float(v[3]) >= 0 else None), "assemble_ms_per_frame": float(v[4]),
                      "host_ms_per_frame_in_loop": float(v[5]), "batches_gathered_twice": int(v[6])} for v in (t_.cpu().tolist() for t_ in allr)]
+    # N > 1 control (after the timed region): the same number of WHOLE frames on every rank, no exchange at all -- what `--parallel frames`
+    # times, N x one GPU by construction.  Beside `value` it separates what the tile-sharded path loses to its collective from what a rank
+    # loses to anything else (a busy host, a slow device).  The collective part is unconditional: a rank whose control fails reports NaN.
+    control = None
+    if not solo:
+        c_ms = float("nan")
+        try:
+            c_ctx = []
+            for _ in range(2):
+                rc = pkg.Renderer(local_rank)
+                rc.set_gaussians(g)
+                rc.set_camera_view(w, h, view) if not args.plane_arrays else rc.set_plane(w, h, *cam.plane())
+                rc.set_options(pkg.EXP_VCL, pkg.ERF_AS, args.cull_eps)
+                rc.set_cull_prune(args.cull_prune)
+                rc.set_table_step(args.table_step)
+                rc.set_shard(0, 1)
+                rc.tile_gaussians_device(tw, th, view, 0)                 # sizes the tile grid (one-time host sync)
+                c_ctx.append(rc)
+            c_img = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in c_ctx]
+            c_st = [torch.cuda.Stream() for _ in c_ctx]
+            c_fr = [rc.frame_call(tw, th, view, origin, pack) for rc in c_ctx]
+            for i_ in range(8):                                           # set-up: the library's per-context feedback settles
+                c_fr[i_ % 2](c_img[i_ % 2].data_ptr(), c_st[i_ % 2].cuda_stream)
+            torch.cuda.synchronize()
+        except Exception as e_:                                           # (reported, never raised: the ranks must reach the barrier together)
+            c_fr = None
+            control = {"error": repr(e_)[:200]}
+        dist.barrier()
+        if c_fr is not None:
+            t2 = time.perf_counter()
+            for i_ in range(args.steps):
+                c_fr[i_ % 2](c_img[i_ % 2].data_ptr(), c_st[i_ % 2].cuda_stream)
+            for s_ in c_st:
+                s_.synchronize()
+            c_ms = (time.perf_counter() - t2) * 1e3
+        c_t = torch.tensor([c_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        allc = [torch.zeros_like(c_t) for _ in range(world)]
+        dist.all_gather(allc, c_t)
+        c_all = [float(t_.item()) for t_ in allc]
+        if control is None and all(v == v for v in c_all):
+            control = {"what": "every rank renders --steps whole frames on its own (two in flight), no collective: `--parallel frames`",
+                       "ms_per_rank": c_all, "value": w * h * args.steps * world / (max(c_all) * 1e-3) / 1e6, "scaling": "weak"}
+        elif control is None:
+            control = {"error": "a rank's control loop failed", "ms_per_rank": c_all}
+        if c_fr is not None:
+            for rc in c_ctx:
+                rc.close()
     r.enable_kernel_timing(1)
     run(max(50, min(args.steps, 100)), 1, serial=True)
     barrier()
@@ -771,7 +818,7 @@ def main():
             # the same loop with one context: frame k+1 starts when frame k is done
             # the same loop at exact settings, and what the timed settings deviate by (checked by the oracle below: "parity")
             "exact_settings": exact,
-            "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "per_rank": per_rank,
+            "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "frame_parallel_control": control, "per_rank": per_rank,
                             "per_rank_note": "a repeat of the timed loop with phase timers on (after the timed region); gather = from enqueue "
                                              "until the frame stream may use the result (upper bound of the collective; its own duration "
                                              "where TORCH_NCCL_ENABLE_TIMING=1 makes the backend keep it)"} if world > 1 else None),

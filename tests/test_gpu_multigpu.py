@@ -332,3 +332,6 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
         assert pr["render_ms_per_frame"] > 0 and pr["gather_ms_per_frame_upper_bound"] > 0 and pr["host_ms_per_frame_in_loop"] > 0
         assert pr["batches_gathered_twice"] == res["config"]["shard_transport"]["batches_gathered_twice"] or pr["rank"] != 0
     assert col["per_rank"][0]["assemble_ms_per_frame"] > 0 and col["per_rank"][1]["assemble_ms_per_frame"] == 0
+    # the control beside it: whole frames on every rank, no exchange (N x one GPU by construction; here both ranks share one GPU)
+    ctl = col["frame_parallel_control"]
+    assert ctl["scaling"] == "weak" and ctl["value"] > 0 and len(ctl["ms_per_rank"]) == 2 and all(v > 0 for v in ctl["ms_per_rank"])
