@@ -591,7 +591,11 @@ __device__ __forceinline__ void build_tile_lists_body(const BinArgs &P, const Fu
             const uint64_t pix = (uint64_t)(tx * P.tile_w + pxt) + (uint64_t)P.stride * (ty * P.tile_h + pyt);
             if (pxt < P.tile_w && pyt < P.tile_h && pix + 3 < npix) {
                 const uint64_t o = F.O.compact ? ((uint64_t)lt * P.tile_h + pyt) * P.tile_w + pxt : pix;
-                *reinterpret_cast<uint4 *>(F.O.image + o) = make_uint4(zero_px, zero_px, zero_px, zero_px);
+                {   // non-temporal: 16 MB of background per 2048^2 frame that nobody reads again before the host does -- streamed past the
+                    // L2 instead of ending up as its dirty lines (two frames in flight 20.7 -> 20.1 us, serial frame 31.2 -> 30.9)
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((u32x4){ zero_px, zero_px, zero_px, zero_px }, reinterpret_cast<u32x4 *>(F.O.image + o));
+                }
             }
         }
     } else {
